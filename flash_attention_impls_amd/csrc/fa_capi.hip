@@ -1,0 +1,162 @@
+// C-ABI launcher for the gfx950 FlashAttention forward kernels (see include/fa_mi355.h).
+//
+// Host-side counterpart of the reference's launchers:
+//   _FlashAttnFn.forward                 code/triton_fa2/FA2-triton.py:175-205
+//   flash_attn_cutlass_forward<D>        code/cutlass_cuda_fa1/run/flash_attn_cutlass.cu:457-515
+//   flash_attention_cutlass_dispatch     code/cutlass_cuda_fa1/run/flash_attn_cutlass.cu:519-544
+// Differences by design: int status + thread-local message instead of fprintf and a silent
+// no-op on unsupported head_dim (:540-542); no first-call banner / static bool (:487-502).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/fa_mi355.h"
+#include "fa_fwd_kernel.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+template <class T, int D, bool CAUSAL>
+int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::lds_bytes<D>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel<T, D, CAUSAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel<T, D, CAUSAL>), dim3(grid), dim3(fa::kThreads), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+template <class T, int D>
+int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
+{
+    return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
+}
+
+int grid_for(int B, int H, int S)
+{
+    const long long bh = (long long)B * H;
+    const long long nqb = (S + fa::kBM - 1) / fa::kBM;
+    const long long g = ((bh + 7) / 8) * 8 * nqb;     // heads padded to a multiple of 8 XCD groups
+    return g > 0x7FFFFFFFll ? -1 : (int)g;
+}
+
+bool set_strides(const int64_t* s, int H, int S, int D, long long& sb, long long& sh, long long& ss)
+{
+    if (s == nullptr) { ss = D; sh = (long long)S * D; sb = (long long)H * S * D; return true; }
+    sb = s[0]; sh = s[1]; ss = s[2];
+    return sb >= 0 && sh >= 0 && ss >= D;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fa_version(void) { return FA_VERSION; }
+
+const char* fa_last_error(void) { return g_err; }
+
+int fa_supported(int dtype, int head_dim)
+{
+    if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16) return 0;
+    return (head_dim == 64 || head_dim == 128) ? 1 : 0;
+}
+
+int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* grid, int* block, int* lds_bytes)
+{
+    (void)causal;
+    if (!fa_supported(dtype, D)) return fail(FA_ERR_BAD_HEAD_DIM, "unsupported (dtype=%d, head_dim=%d)", dtype, D);
+    if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape");
+    if (grid) *grid = grid_for(B, H, S);
+    if (block) *block = fa::kThreads;
+    if (lds_bytes) *lds_bytes = (D == 128) ? fa::lds_bytes<128>() : fa::lds_bytes<64>();
+    return FA_OK;
+}
+
+int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+           int B, int H, int S, int D,
+           const int64_t* q_strides, const int64_t* k_strides,
+           const int64_t* v_strides, const int64_t* o_strides,
+           int dtype, int causal, float softmax_scale,
+           const float* descale, void* stream)
+{
+    g_err[0] = 0;
+    (void)descale;
+    if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_FP8_E4M3)
+        return fail(FA_ERR_BAD_DTYPE, "unknown dtype code %d", dtype);
+    if (D != 64 && D != 128)
+        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (compiled: 64, 128)", D);
+    if (!fa_supported(dtype, D))
+        return fail(FA_ERR_BAD_DTYPE, "no kernel compiled for dtype=%d head_dim=%d", dtype, D);
+    if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
+    if (B == 0 || H == 0 || S == 0) return FA_OK;        // empty problem: nothing to do
+    if (!q || !k || !v || !o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
+
+    fa::FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
+    p.B = B; p.H = H; p.S = S;
+    p.nqb = (S + fa::kBM - 1) / fa::kBM;
+    p.bh = B * H;
+    if (!set_strides(q_strides, H, S, D, p.q_sb, p.q_sh, p.q_ss) ||
+        !set_strides(k_strides, H, S, D, p.k_sb, p.k_sh, p.k_ss) ||
+        !set_strides(v_strides, H, S, D, p.v_sb, p.v_sh, p.v_ss) ||
+        !set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss))
+        return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
+    const long long esz = 2;
+    const long long strides[] = {p.q_sb, p.q_sh, p.q_ss, p.k_sb, p.k_sh, p.k_ss,
+                                 p.v_sb, p.v_sh, p.v_ss, p.o_sb, p.o_sh, p.o_ss};
+    for (long long s : strides)
+        if ((s * esz) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "stride %lld elements is not 16-byte aligned", s);
+    const void* ptrs[] = {q, k, v, o};
+    for (const void* ptr : ptrs)
+        if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "tensor base pointer not 16-byte aligned");
+    // 32-bit buffer offsets inside one (batch, head) slice, with room for two prefetched tiles
+    const long long max_ss = std::max(std::max(p.q_ss, p.k_ss), std::max(p.v_ss, p.o_ss));
+    if (((long long)S + 4 * fa::kBN) * max_ss * esz >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", S, max_ss);
+
+    const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
+    p.scale = scale;
+    p.scale_log2 = scale * 1.4426950408889634f;
+
+    const int grid = grid_for(B, H, S);
+    if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool c = causal != 0;
+    if (dtype == FA_DTYPE_BF16)
+        return D == 128 ? launch_c<fa::TypeBF16, 128>(p, grid, c, s) : launch_c<fa::TypeBF16, 64>(p, grid, c, s);
+    if (dtype == FA_DTYPE_FP16)
+        return D == 128 ? launch_c<fa::TypeF16, 128>(p, grid, c, s) : launch_c<fa::TypeF16, 64>(p, grid, c, s);
+    return fail(FA_ERR_BAD_DTYPE, "dtype %d not compiled", dtype);
+}
+
+int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,
+                    int batch_size, int num_heads, int seq_len, int head_dim,
+                    int dtype, void* stream)
+{
+    return fa_fwd(Q, K, V, O, nullptr, batch_size, num_heads, seq_len, head_dim,
+                  nullptr, nullptr, nullptr, nullptr, dtype, /*causal=*/0, /*scale=*/0.f, nullptr, stream);
+}
+
+}  // extern "C"

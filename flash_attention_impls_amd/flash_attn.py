@@ -1,0 +1,185 @@
+"""Python host side of the MI355X FlashAttention forward: the reference's operator entry
+point re-implemented over the C-ABI HIP library (``include/fa_mi355.h``).
+
+Mirrors, for the forward path only:
+  * ``flash_attention(q, k, v, causal=False)``   code/triton_fa2/FA2-triton.py:240-244
+    (positional (B,H,N,D) tensors; fp32 inputs are computed in fp16 and cast back :241-244)
+  * ``_FlashAttnFn.forward``                      code/triton_fa2/FA2-triton.py:175-205
+    (asserts ``is_cuda`` and ``D % 16 == 0 and D <= 128`` :176-178; allocates O and the
+    softmax statistics; launches on the current stream; scale 1/sqrt(D) :183)
+
+The north-star spells the entry ``flash_attn``; the reference spells it ``flash_attention``.
+Both names are exported and are the same function.
+
+There is NO CPU fallback: CPU tensors raise (as the reference's ``assert q.is_cuda`` does) and a
+missing HIP library raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import threading
+
+import torch
+
+from . import _build
+
+FA_DTYPE_BF16 = 0
+FA_DTYPE_FP16 = 1
+FA_DTYPE_FP8_E4M3 = 2
+
+_SUPPORTED_HEAD_DIMS = (64, 128)
+
+
+class FlashAttnArgumentError(ValueError, AssertionError):
+    """Bad argument to flash_attn.  Subclasses AssertionError because the reference signals
+    the same conditions with ``assert`` (FA2-triton.py:176-178)."""
+
+
+_lib_lock = threading.Lock()
+_lib_handle = None
+
+
+def _declare(lib):
+    c = ctypes
+    lib.fa_version.restype = c.c_int
+    lib.fa_version.argtypes = []
+    lib.fa_supported.restype = c.c_int
+    lib.fa_supported.argtypes = [c.c_int, c.c_int]
+    lib.fa_last_error.restype = c.c_char_p
+    lib.fa_last_error.argtypes = []
+    lib.fa_fwd.restype = c.c_int
+    lib.fa_fwd.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                           c.c_int, c.c_int, c.c_int, c.c_int,
+                           c.POINTER(c.c_int64), c.POINTER(c.c_int64),
+                           c.POINTER(c.c_int64), c.POINTER(c.c_int64),
+                           c.c_int, c.c_int, c.c_float,
+                           c.POINTER(c.c_float), c.c_void_p]
+    lib.fa_fwd_dispatch.restype = c.c_int
+    lib.fa_fwd_dispatch.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                                    c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p]
+    lib.fa_fwd_launch_info.restype = c.c_int
+    lib.fa_fwd_launch_info.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int,
+                                       c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    return lib
+
+
+def load_library(path: str | None = None):
+    """Load (building first if the in-tree .so is missing or stale and hipcc is available)
+    the C-ABI library.  Raises RuntimeError if it cannot be produced -- never falls back."""
+    global _lib_handle
+    with _lib_lock:
+        if _lib_handle is not None and path is None:
+            return _lib_handle
+        p = path or _build.LIB_PATH
+        if path is None and _build.is_stale():
+            try:
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                if not os.path.exists(p):
+                    raise RuntimeError(
+                        f"HIP library {p} is missing and could not be built ({e}); "
+                        "run `python -c 'import __graft_entry__ as g; g.build()'`") from e
+        try:
+            lib = _declare(ctypes.CDLL(p))
+        except OSError as e:
+            raise RuntimeError(f"cannot load HIP library {p}: {e}") from e
+        if path is None:
+            _lib_handle = lib
+        return lib
+
+
+def _dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return FA_DTYPE_BF16
+    if dt == torch.float16:
+        return FA_DTYPE_FP16
+    if dt == torch.float8_e4m3fn:
+        return FA_DTYPE_FP8_E4M3
+    raise FlashAttnArgumentError(f"unsupported dtype {dt}; expected bfloat16, float16, float32 "
+                                 "(computed in float16 like the reference) or float8_e4m3fn")
+
+
+def _strides3(t: torch.Tensor):
+    sb, sh, ss, sd = t.stride()
+    return (ctypes.c_int64 * 3)(sb, sh, ss)
+
+
+def _kernel_ready(t: torch.Tensor) -> torch.Tensor:
+    """Return t itself if the kernel can address it (unit head_dim stride, 16-byte aligned
+    rows), otherwise a contiguous copy (the reference passes arbitrary strides to Triton,
+    FA2-triton.py:190-193; the copy keeps that contract)."""
+    es = t.element_size()
+    ok = (t.stride(3) == 1 and t.data_ptr() % 16 == 0
+          and all((s * es) % 16 == 0 and s >= 0 for s in t.stride()[:3])
+          and t.stride(2) >= t.shape[3])
+    return t if ok else t.contiguous()
+
+
+def check_args(q, k, v) -> None:
+    """Argument validation shared with tests (pure host logic, no GPU needed)."""
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if q.dim() != 4:
+        raise FlashAttnArgumentError(f"q must be (B, H, N, D); got shape {tuple(q.shape)}")
+    if k.shape != q.shape or v.shape != q.shape:
+        raise FlashAttnArgumentError(
+            f"q, k, v must have identical shapes; got {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise FlashAttnArgumentError(f"q, k, v must share a dtype; got {q.dtype}, {k.dtype}, {v.dtype}")
+    if k.device != q.device or v.device != q.device:
+        raise FlashAttnArgumentError("q, k, v must be on the same device")
+    if not q.is_cuda:                                   # FA2-triton.py:176
+        raise FlashAttnArgumentError(
+            "flash_attn needs GPU (ROCm 'cuda') tensors; there is no CPU path "
+            "(reference: assert q.is_cuda, FA2-triton.py:176)")
+    D = q.shape[3]
+    if D % 16 != 0 or D > 128:                          # FA2-triton.py:178
+        raise FlashAttnArgumentError(f"head_dim must satisfy D % 16 == 0 and D <= 128; got {D}")
+    if D not in _SUPPORTED_HEAD_DIMS:
+        raise FlashAttnArgumentError(
+            f"head_dim {D} has no compiled gfx950 kernel yet (available: {_SUPPORTED_HEAD_DIMS})")
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
+               softmax_scale: float | None = None, return_lse: bool = False,
+               descale: tuple[float, float, float] | None = None):
+    """Fused attention forward on MI355X.  ``q, k, v``: (B, H, N, D) GPU tensors.
+
+    Returns O with q's dtype (fp32 inputs are computed in fp16 and cast back, like the
+    reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural
+    log-sum-exp of the scaled scores (the reference keeps m and l instead: lse = m + ln l).
+    """
+    check_args(q, k, v)
+    orig_dtype = q.dtype
+    if q.dtype == torch.float32:                         # FA2-triton.py:241-243
+        q, k, v = q.half(), k.half(), v.half()
+    code = _dtype_code(q.dtype)
+    lib = load_library()
+    B, H, N, D = q.shape
+    if not lib.fa_supported(code, D):
+        raise FlashAttnArgumentError(f"no gfx950 kernel compiled for dtype={q.dtype}, head_dim={D}")
+    q, k, v = _kernel_ready(q), _kernel_ready(k), _kernel_ready(v)
+    out_dtype = torch.bfloat16 if code == FA_DTYPE_FP8_E4M3 else q.dtype
+    o = torch.empty((B, H, N, D), dtype=out_dtype, device=q.device)        # FA2-triton.py:179
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
+    if B * H * N > 0:
+        scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(D)   # :183
+        dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
+        with torch.cuda.device(q.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
+                            lse.data_ptr() if lse is not None else None,
+                            B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                            code, 1 if causal else 0, scale, dsc, stream)
+        if rc != 0:
+            raise RuntimeError(f"fa_fwd failed ({rc}): {lib.fa_last_error().decode()}")
+    if orig_dtype == torch.float32:
+        o = o.to(orig_dtype)                              # FA2-triton.py:244
+    return (o, lse) if return_lse else o
+
+
+# the reference's spelling (FA2-triton.py:240)
+flash_attention = flash_attn

@@ -1,0 +1,99 @@
+/*
+ * fa_mi355.h -- C ABI of the MI355X (gfx950) FlashAttention-forward library.
+ *
+ * This is the drop-in boundary for the reference's forward path.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference repo
+ * santiweide/flash-attention-impls @ 2025-10-31):
+ *
+ *   fa_fwd                 <- _FlashAttnFn.forward + _fwd_kernel launch
+ *                             code/triton_fa2/FA2-triton.py:175-205 (tensors + strides in,
+ *                             O / m,l out; here LSE = m + ln l replaces the m,l pair)
+ *   fa_fwd_dispatch        <- flash_attention_cutlass_dispatch(Q,K,V,O,B,H,N,D,stream)
+ *                             code/cutlass_cuda_fa1/run/flash_attn_cutlass.cu:519-544
+ *                             (same argument order; contiguous [B,H,N,D]; int status
+ *                             instead of void + fprintf)
+ *   fa_supported           <- the head_dim switch of that dispatcher (:530-543) and the
+ *                             asserts of FA2-triton.py:176-178
+ *   fa_last_error          <- fprintf(stderr, ...) at flash_attn_cutlass.cu:510-514,540-542
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers owned by the caller; the library never
+ *     allocates, frees or synchronises (flash_attn_cutlass.cu has the same ownership rule);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value 0 = success, negative = error (see FA_ERR_*); a human-readable message
+ *     for the calling thread is available from fa_last_error();
+ *   - re-entrant: no mutable global state besides one-time kernel attribute setup.
+ */
+#ifndef FA_MI355_H
+#define FA_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_VERSION 100          /* 0.1.0 */
+
+/* element types of Q/K/V (and of O unless stated otherwise) */
+#define FA_DTYPE_BF16     0
+#define FA_DTYPE_FP16     1
+#define FA_DTYPE_FP8_E4M3 2     /* OCP e4m3fn inputs, bf16 output */
+
+#define FA_OK               0
+#define FA_ERR_BAD_DTYPE   -1
+#define FA_ERR_BAD_HEAD_DIM -2
+#define FA_ERR_BAD_SHAPE   -3
+#define FA_ERR_BAD_STRIDE  -4
+#define FA_ERR_NULL_PTR    -5
+#define FA_ERR_LAUNCH      -6
+#define FA_ERR_TOO_LARGE   -7
+
+/* Library version (FA_VERSION of the build). */
+int fa_version(void);
+
+/* 1 if (dtype, head_dim) has a compiled kernel, else 0. */
+int fa_supported(int dtype, int head_dim);
+
+/* Message describing the last error on the calling thread ("" if none). */
+const char* fa_last_error(void);
+
+/*
+ * Fused attention forward:  O = softmax(scale * Q K^T  [+ causal mask]) V
+ *
+ *   q, k, v : [B, H, S, D] with element strides (stride_b, stride_h, stride_s); the
+ *             head_dim stride must be 1.  A NULL strides pointer means contiguous.
+ *             Base pointers and row strides must be 16-byte aligned.
+ *   o       : same logical shape; element type = dtype (bf16 for FA_DTYPE_FP8_E4M3).
+ *   lse     : nullable; contiguous [B, H, S] fp32, natural log-sum-exp of the scaled scores.
+ *   causal  : non-zero = mask keys j > query i (top-left aligned, FA2-triton.py:70-73).
+ *   softmax_scale : <= 0 selects 1/sqrt(D) (FA2-triton.py:183).
+ *   descale : nullable, HOST pointer to 3 floats {q,k,v} per-tensor dequantisation scales,
+ *             used with FA_DTYPE_FP8_E4M3 only (NULL = 1.0).
+ */
+int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+           int B, int H, int S, int D,
+           const int64_t* q_strides, const int64_t* k_strides,
+           const int64_t* v_strides, const int64_t* o_strides,
+           int dtype, int causal, float softmax_scale,
+           const float* descale, void* stream);
+
+/*
+ * Contiguous [B,H,N,D] convenience entry with the reference dispatcher's argument order
+ * (flash_attn_cutlass.cu:519-529), non-causal, scale 1/sqrt(D).
+ */
+int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,
+                    int batch_size, int num_heads, int seq_len, int head_dim,
+                    int dtype, void* stream);
+
+/*
+ * Launch geometry that fa_fwd would use (for benches / profilers): writes grid size,
+ * block size and dynamic LDS bytes.  Returns FA_OK or an error.
+ */
+int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal,
+                       int* grid, int* block, int* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA_MI355_H */

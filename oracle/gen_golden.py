@@ -1,0 +1,132 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own code.  Run in the build
+container only (needs /root/reference); the GPU box never runs this.
+
+  python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+What is executed from the reference (imported as a module, nothing copied):
+  * sdpa_reference(q,k,v,causal)   code/triton_fa2/FA2-triton.py:311-323   -> "o"
+  * _fwd_kernel under TRITON_INTERPRET=1 for D<=64 (the reference kernel is wrong
+    for D=128: BLOCK_D_=min(64,D), FA2-triton.py:20,198)                   -> "m","l","o_kernel"
+
+Inputs: g = torch.Generator().manual_seed(seed); q,k,v = randn(B,H,S,D, generator=g)
+in that order (fp32), optionally multiplied by `mul`, then cast to the case dtype.
+bf16 tensors are stored as uint16 bit patterns, fp8-e4m3fn as uint8 bit patterns.
+"lse" is computed in float64 from the dtype-rounded inputs (log-sum-exp of
+scale*q.k over unmasked keys); where the interpreted reference kernel ran,
+lse == m + log(l) is asserted to 2e-3 (fp16 kernel arithmetic).
+"""
+import importlib.util
+import math
+import os
+import sys
+
+os.environ.setdefault("TRITON_INTERPRET", "1")
+
+import numpy as np
+import torch
+
+REF = "/root/reference/code/triton_fa2/FA2-triton.py"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+CASES = [
+    # name, B,H,S,D, dtype, causal, seed, mul, run_triton_kernel
+    ("cfg1_fp32_nc",        1, 1, 128, 64,  "fp32", False, 0, 1.0, False),
+    ("cfg1_fp32_causal",    1, 1, 128, 64,  "fp32", True,  0, 1.0, False),
+    ("bf16_d64_nc",         2, 2, 256, 64,  "bf16", False, 0, 1.0, False),
+    ("bf16_d128_causal",    2, 2, 256, 128, "bf16", True,  0, 1.0, False),
+    ("bf16_d128_ragged",    1, 2, 200, 128, "bf16", True,  1, 1.0, False),
+    ("bf16_d64_ragged_nc",  1, 3, 77,  64,  "bf16", False, 2, 1.0, False),
+    ("fp16_d64_x8",         1, 1, 64,  64,  "fp16", False, 3, 8.0, True),
+    ("fp16_d64_causal",     1, 2, 256, 64,  "fp16", True,  4, 1.0, True),
+    ("fp16_d128_nc",        1, 2, 320, 128, "fp16", False, 5, 1.0, False),
+    ("bf16_d128_s1",        1, 1, 1,   128, "bf16", True,  6, 1.0, False),
+    ("bf16_d128_s513",      1, 1, 513, 128, "bf16", True,  7, 1.0, False),
+    ("fp8_d128_nc",         1, 2, 256, 128, "fp8",  False, 8, 1.0, False),
+    ("fp8_d128_causal",     1, 2, 256, 128, "fp8",  True,  9, 1.0, False),
+]
+
+TORCH_DT = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("fa2_triton_ref", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def to_storage(t, dtype):
+    if dtype == "bf16":
+        return t.view(torch.uint16).numpy().copy()
+    if dtype == "fp8":
+        return t.view(torch.uint8).numpy().copy()
+    return t.numpy().copy()
+
+
+def main():
+    ref = load_reference()
+    os.makedirs(OUT, exist_ok=True)
+    for (name, B, H, S, D, dtype, causal, seed, mul, run_kernel) in CASES:
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(B, H, S, D, generator=g) * mul
+        k = torch.randn(B, H, S, D, generator=g) * mul
+        v = torch.randn(B, H, S, D, generator=g) * mul
+        extra = {}
+        if dtype == "fp8":
+            # per-tensor scale amax/448, e4m3fn storage; the oracle output
+            # is SDPA of the DEQUANTISED tensors (descale * fp8 value) in fp32.
+            ds = [float(t.abs().max()) / 448.0 for t in (q, k, v)]
+            q8, k8, v8 = [(t / s).to(torch.float8_e4m3fn) for t, s in zip((q, k, v), ds)]
+            qd, kd, vd = [t8.to(torch.float32) * s for t8, s in zip((q8, k8, v8), ds)]
+            o = ref.sdpa_reference(qd, kd, vd, causal=causal)          # fp32 result
+            store = {"q": to_storage(q8, "fp8"), "k": to_storage(k8, "fp8"), "v": to_storage(v8, "fp8"),
+                     "descale": np.asarray(ds, np.float32), "o": o.numpy().copy()}
+            qf, kf, vf = qd, kd, vd
+        else:
+            dt = TORCH_DT[dtype]
+            qx, kx, vx = q.to(dt), k.to(dt), v.to(dt)
+            o = ref.sdpa_reference(qx, kx, vx, causal=causal)          # dtype of input (:323)
+            store = {"q": to_storage(qx, dtype), "k": to_storage(kx, dtype), "v": to_storage(vx, dtype),
+                     "o": to_storage(o, dtype)}
+            # un-rounded fp32 result of the same call path (reference casts at :323 only)
+            o32 = ref.sdpa_reference(qx.float(), kx.float(), vx.float(), causal=causal)
+            store["o_f32"] = o32.numpy().copy()
+            qf, kf, vf = qx.float(), kx.float(), vx.float()
+        # float64 LSE from the rounded inputs
+        scale = 1.0 / math.sqrt(D)
+        s = torch.einsum("bhid,bhjd->bhij", qf.double(), kf.double()) * scale
+        if causal:
+            i = torch.arange(S)[:, None]
+            j = torch.arange(S)[None, :]
+            s = s.masked_fill(j > i, float("-inf"))
+        lse = torch.logsumexp(s, dim=-1)
+        store["lse"] = lse.numpy().astype(np.float32)
+        if run_kernel:
+            assert dtype == "fp16" and D <= 64
+            o_k = torch.empty_like(qx)
+            m = torch.empty(B, H, S, dtype=torch.float32)
+            l = torch.empty(B, H, S, dtype=torch.float32)
+            grid = (B * H, (S + ref.BLOCK_M - 1) // ref.BLOCK_M)
+            ref._fwd_kernel[grid](
+                qx, kx, vx, o_k, m, l, B, H, S, D,
+                *qx.stride(), *kx.stride(), *vx.stride(), *o_k.stride(),
+                *m.stride(), *l.stride(), scale,
+                is_causal=causal, BLOCK_M_=ref.BLOCK_M, BLOCK_N_=ref.BLOCK_N,
+                BLOCK_D_=min(ref.BLOCK_D, D))
+            extra["m"] = m.numpy().copy()
+            extra["l"] = l.numpy().copy()
+            extra["o_kernel"] = o_k.numpy().copy()
+            err = float((m + torch.log(l) - lse.float()).abs().max())
+            assert err < 2e-3, (name, err)
+            print(f"  {name}: reference _fwd_kernel m+log(l) vs f64 lse: {err:.2e}; "
+                  f"o_kernel vs sdpa: {float((o_k.float()-o.float()).abs().max()):.2e}")
+        meta = dict(B=B, H=H, S=S, D=D, causal=int(causal), seed=seed, mul=mul)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), dtype=np.array(dtype),
+                            **{k_: np.array(v_) for k_, v_ in meta.items()}, **store, **extra)
+        print(f"{name}: o.sum={float(o.float().sum()):.6f} |o|.sum={float(o.float().abs().sum()):.6f}")
+
+
+if __name__ == "__main__":
+    if not os.path.exists(REF):
+        sys.exit("reference not present: golden vectors can only be generated in the build container")
+    main()
