@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused attention forward TFLOP/s (+ % of the gfx950 bf16 MFMA roofline)
+at BASELINE.json's configuration (B=8, H=32, S=4096, D=128, bf16, causal) per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+* a "step" = one launch of the fused forward over one (8,32,4096,128) batch of synthetic
+  N(0,1) Q/K/V already resident in HBM (seed 0 + rank; reference recipe FA2-triton.py:329,335-337);
+* N>1: one process per GPU; the (batch x head) units are partitioned over ranks with NO
+  data-path collective (each rank owns its own 8-batch shard -> "weak" scaling, the cfg5
+  layout: 64 batches over 8 GPUs); the final all-gather of O over RCCL is measured after the
+  timed region and reported separately (`gather`), it is not part of `value`;
+* timing: W warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both
+  sides, max over ranks; `value` = whole-job algorithmic FLOPs / that time;
+* `roofline`: per-launch HIP-event time of the kernel on its own stream vs dense bf16 MFMA peak;
+* `cpu_baseline`: the oracle's port of the reference's CPU-runnable path (sdpa_reference ==
+  torch CPU SDPA, FA2-triton.py:311-323) on a bounded sub-batch, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"bf16": 2516.6, "fp16": 2516.6}     # 256 CU x 4096 FLOP/clk x 2.4 GHz (dense)
+HBM_PEAK_GBPS = 8000.0
+
+WORKLOADS = {
+    "cfg3": dict(B=8, H=32, S=4096, D=128, dtype="bf16", causal=True),
+    "cfg2": dict(B=4, H=8, S=1024, D=64, dtype="bf16", causal=False),
+    "cfg4": dict(B=1, H=16, S=16384, D=128, dtype="bf16", causal=True),
+    "cfg3nc": dict(B=8, H=32, S=4096, D=128, dtype="bf16", causal=False),
+}
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, target_s):
+    """Oracle leg (test infrastructure used as the checker/baseline only, never shipped)."""
+    from oracle import attn_oracle as orc
+    from flash_attention_impls_amd.bench_utils import attn_flops
+    cores = os.cpu_count() or 1
+    B, H, S, D, causal = 1, min(4, w["H"]), w["S"], w["D"], w["causal"]
+    dt = DT[w["dtype"]]
+    t_probe, threads = orc.time_cpu_sdpa(B, H, S, D, dt, causal, iters=1, threads=cores)
+    # scale the head count so the sample takes about target_s (bounded by the full head count)
+    h_full = max(1, min(w["H"], int(H * (target_s / 3.0) / max(t_probe, 1e-4))))
+    t, threads = orc.time_cpu_sdpa(1, h_full, S, D, dt, causal, iters=3, threads=cores)
+    fl = attn_flops(1, h_full, S, D, causal)
+    return {"value": fl / t / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"torch CPU SDPA (oracle port of sdpa_reference) on B=1 H={h_full} S={S} D={D} "
+                      f"{w['dtype']} causal={int(causal)}, 3 iters, {t * 1e3:.1f} ms/iter; attention cost is linear in B*H",
+            "ms_per_iter": t * 1e3}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist = None
+
+    import flash_attention_impls_amd as fa
+    from flash_attention_impls_amd.bench_utils import attn_bytes, attn_flops
+    lib = fa.load_library()           # raises if the HIP extension is missing
+
+    w = WORKLOADS[args.workload]
+    B, H, S, D, causal = w["B"], w["H"], w["S"], w["D"], w["causal"]
+    dt = DT[w["dtype"]]
+    torch.manual_seed(0 + rank)
+    q = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+    k = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+    v = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+
+    # parity gate (small shape, oracle as the checker) before any timing is accepted
+    parity = None
+    if rank == 0:
+        from oracle import attn_oracle as orc
+        g = torch.Generator().manual_seed(1)
+        qs, ks, vs = (torch.randn(1, 2, 333, D, generator=g).to(dt) for _ in range(3))
+        o_s = fa.flash_attn(qs.to(dev), ks.to(dev), vs.to(dev), causal).float().cpu()
+        ref = orc.sdpa_oracle(qs.float(), ks.float(), vs.float(), causal)
+        parity = float((o_s - ref).abs().max())
+        tol = 1.6e-2 if w["dtype"] == "bf16" else 2e-3
+        if not parity <= tol * max(1.0, float(ref.abs().max())):
+            sys.exit(f"parity gate failed: max|o-ref|={parity}")
+
+    def step():
+        return fa.flash_attn(q, k, v, causal)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-launch kernel time with HIP events on the launching stream (torch's current stream)
+    n_ev = min(args.steps, 50)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    kt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    kernel_ms = sum(kt) / len(kt)
+
+    flops_rank = attn_flops(B, H, S, D, causal)
+    bytes_rank = attn_bytes(B, H, S, D)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * flops_rank / (elapsed / args.steps) / 1e12
+    peak = MFMA_PEAK_TFLOPS[w["dtype"]]
+    achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
+
+    gather = None
+    if dist is not None and not args.no_gather:
+        o = step()
+        full = torch.empty((world * B, H, S, D), dtype=o.dtype, device=dev)
+        for _ in range(2):
+            dist.all_gather_into_tensor(full, o)
+        barrier()
+        tg = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_gather_into_tensor(full, o)
+        barrier()
+        g_ms = (time.perf_counter() - tg) / reps * 1e3
+        shard = o.numel() * o.element_size()
+        gather = {"ms": g_ms, "shard_MiB": shard / 2 ** 20,
+                  "recv_GBps_per_rank": (world - 1) * shard / (g_ms * 1e-3) / 1e9,
+                  "note": "all_gather_into_tensor of O over RCCL, outside the timed region"}
+
+    if rank == 0:
+        out = {
+            "metric": "attn_fwd_tflops", "value": value, "unit": "TFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
+            "config": {"workload": f"{args.workload}: B={B} H={H} S={S} D={D} {w['dtype']} "
+                                   f"{'causal' if causal else 'non-causal'} per GPU (BASELINE.json metric config)",
+                       "B_per_gpu": B, "H": H, "S": S, "D": D, "causal": causal,
+                       "sharding": f"batch x head units split over {world} rank(s), no data-path collective",
+                       "flops_rule": "4*B*H*S^2*D, halved when causal (FA2 convention)"},
+            "pct_mfma_peak": 100.0 * value / (world * peak),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel_ms_avg": kernel_ms, "kernel_ms_min": kt[0],
+                         "algorithmic_flops_per_launch": flops_rank,
+                         "algorithmic_bytes_per_launch": bytes_rank,
+                         "algorithmic_GBps": bytes_rank / (kernel_ms * 1e-3) / 1e9,
+                         "hbm_frac": bytes_rank / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "parity_max_abs_err_small_case": parity,
+            "device": torch.cuda.get_device_name(dev),
+            "lib_version": lib.fa_version(),
+        }
+        if gather is not None:
+            out["gather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "TFLOP/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+import ctypes
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# stated floating-point tolerances (BASELINE.md §4 / SURVEY.md §4): |o - ref| <= tol * max(1, |ref|)
+TOL = {"bf16": 1.6e-2, "fp16": 2e-3, "fp32": 2e-3}   # fp32 inputs are computed in fp16 (FA2-triton.py:241-244)
+FP8_REL_FRO = 5e-2
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    d = {k: z[k] for k in z.files}
+    d["dtype"] = str(d["dtype"])
+    for k in ("B", "H", "S", "D", "causal", "seed"):
+        d[k] = int(d[k])
+    return d
+
+
+def golden_f32(d, key):
+    """fp32 view of a stored tensor (bf16 is stored as uint16 bits, fp8-e4m3fn as uint8 bits)."""
+    a = d[key]
+    if a.dtype == np.uint16:
+        return (a.astype(np.uint32) << 16).view(np.float32)
+    if a.dtype == np.uint8:
+        import torch
+        return torch.from_numpy(a.copy()).view(torch.float8_e4m3fn).to(torch.float32).numpy()
+    return a.astype(np.float32)
+
+
+def golden_torch(d, key, device="cpu"):
+    import torch
+    a = d[key]
+    if a.dtype == np.uint16:
+        t = torch.from_numpy(a.copy()).view(torch.bfloat16)
+    elif a.dtype == np.uint8:
+        t = torch.from_numpy(a.copy()).view(torch.float8_e4m3fn)
+    else:
+        t = torch.from_numpy(a.copy())
+    return t.to(device)
+
+
+@pytest.fixture(scope="session")
+def oracle_clib():
+    """Build (gcc) and load the plain-C oracle restatement."""
+    src = os.path.join(ROOT, "oracle", "attn_ref.c")
+    out_dir = os.path.join(ROOT, "oracle", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liboracle_attn.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, src, "-lm"])
+    lib = ctypes.CDLL(so)
+    c = ctypes
+    fp = c.POINTER(c.c_float)
+    dp = c.POINTER(c.c_double)
+    lib.oracle_attn_fwd_f32.restype = c.c_int
+    lib.oracle_attn_fwd_f32.argtypes = [fp, fp, fp, fp, fp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int,
+                                        c.c_float, c.c_int, c.c_int]
+    lib.oracle_attn_naive_f64.restype = c.c_int
+    lib.oracle_attn_naive_f64.argtypes = [fp, fp, fp, dp, dp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_double]
+    lib.oracle_sym_rel_err.restype = c.c_double
+    lib.oracle_sym_rel_err.argtypes = [fp, fp, c.c_long]
+    return lib
+
+
+def c_oracle_fwd(lib, q, k, v, causal, scale=None, block_m=64, block_n=64):
+    """Run the C oracle on fp32 numpy (B,H,N,D) arrays -> (o, lse)."""
+    q = np.ascontiguousarray(q, np.float32)
+    k = np.ascontiguousarray(k, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    B, H, N, D = q.shape
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+    o = np.empty_like(q)
+    lse = np.empty((B, H, N), np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    rc = lib.oracle_attn_fwd_f32(q.ctypes.data_as(fp), k.ctypes.data_as(fp), v.ctypes.data_as(fp),
+                                 o.ctypes.data_as(fp), lse.ctypes.data_as(fp), B, H, N, D, int(causal),
+                                 float(scale), block_m, block_n)
+    assert rc == 0
+    return o, lse

@@ -1,0 +1,152 @@
+"""CPU: host-side logic, the C-ABI surface, and error behaviour (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import flash_attention_impls_amd as fa
+from flash_attention_impls_amd import _build, dist as fdist
+from flash_attention_impls_amd.bench_utils import attn_bytes, attn_flops
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def declared_symbols():
+    """Every function declared in include/*.h."""
+    syms = []
+    inc = os.path.join(ROOT, "include")
+    for fn in sorted(os.listdir(inc)):
+        if not fn.endswith(".h"):
+            continue
+        text = open(os.path.join(inc, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms += re.findall(r"\b(fa_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(syms))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    lib = fa.load_library()
+    syms = declared_symbols()
+    assert {"fa_fwd", "fa_fwd_dispatch", "fa_version", "fa_supported", "fa_last_error",
+            "fa_fwd_launch_info"} <= set(syms)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ but not exported"
+    assert lib.fa_version() == 100
+    assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
+
+
+def test_supported_matrix():
+    lib = fa.load_library()
+    for dt in (0, 1):
+        assert lib.fa_supported(dt, 64) == 1 and lib.fa_supported(dt, 128) == 1
+        assert lib.fa_supported(dt, 32) == 0 and lib.fa_supported(dt, 256) == 0
+    assert lib.fa_supported(7, 128) == 0
+
+
+def test_capi_error_codes_without_gpu():
+    """Argument errors are detected before any launch: safe to exercise on CPU."""
+    lib = fa.load_library()
+    null = None
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # bad dtype / head_dim / shape / null pointers
+    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 128, null, null, null, null, 9, 0, 0.0, null, null) == -1
+    assert b"dtype" in lib.fa_last_error()
+    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 96, null, null, null, null, 0, 0, 0.0, null, null) == -2
+    assert b"head_dim" in lib.fa_last_error()
+    assert lib.fa_fwd(p, p, p, p, null, -1, 1, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == -3
+    assert lib.fa_fwd(null, p, p, p, null, 1, 1, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == -5
+    # bad strides (seq stride < D; unaligned)
+    bad = (ctypes.c_int64 * 3)(1024, 1024, 64)
+    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 128, bad, null, null, null, 0, 0, 0.0, null, null) == -4
+    odd = (ctypes.c_int64 * 3)(1028, 1028, 129)
+    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 128, odd, null, null, null, 0, 0, 0.0, null, null) == -4
+    # too large for 32-bit buffer offsets
+    huge = (ctypes.c_int64 * 3)(1 << 40, 1 << 36, 1 << 24)
+    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 4096, 128, huge, huge, huge, huge, 0, 0, 0.0, null, null) == -7
+    # empty problems succeed without touching the device
+    assert lib.fa_fwd(null, null, null, null, null, 0, 4, 128, 128, null, null, null, null, 0, 0, 0.0, null, null) == 0
+    assert lib.fa_fwd(null, null, null, null, null, 2, 4, 0, 128, null, null, null, null, 0, 1, 0.0, null, null) == 0
+    assert lib.fa_last_error() == b""
+
+
+def test_launch_info_geometry():
+    lib = fa.load_library()
+    g, b, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.fa_fwd_launch_info(8, 32, 4096, 128, 0, 1, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
+    assert (g.value, b.value, l.value) == (8 * 32 * 16, 512, 65536)      # cfg3
+    assert lib.fa_fwd_launch_info(1, 3, 77, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
+    assert (g.value, b.value, l.value) == (8, 512, 32768)                # heads padded to 8 XCD groups
+    assert lib.fa_fwd_launch_info(1, 1, 8, 48, 0, 0, None, None, None) == -2
+
+
+def test_python_entry_points_and_error_behaviour():
+    assert fa.flash_attention is fa.flash_attn            # FA2-triton.py:240 spelling
+    q = torch.zeros(1, 1, 128, 64)
+    with pytest.raises(AssertionError):                   # reference: assert q.is_cuda (:176)
+        fa.flash_attn(q, q, q)
+    with pytest.raises(ValueError, match="no CPU path"):
+        fa.flash_attn(q, q, q, causal=True)
+    with pytest.raises(TypeError):
+        fa.flash_attn([1], q, q)
+    with pytest.raises(fa.FlashAttnArgumentError, match=r"\(B, H, N, D\)"):
+        fa.check_args(torch.zeros(2, 3, 4), torch.zeros(2, 3, 4), torch.zeros(2, 3, 4))
+    with pytest.raises(fa.FlashAttnArgumentError, match="identical shapes"):
+        fa.check_args(torch.zeros(1, 1, 8, 64), torch.zeros(1, 1, 9, 64), torch.zeros(1, 1, 8, 64))
+    with pytest.raises(fa.FlashAttnArgumentError, match="share a dtype"):
+        fa.check_args(torch.zeros(1, 1, 8, 64), torch.zeros(1, 1, 8, 64, dtype=torch.float16), torch.zeros(1, 1, 8, 64))
+
+
+def test_head_dim_rule_matches_reference_assert():
+    """D % 16 == 0 and D <= 128 (FA2-triton.py:178) is checked before the compiled-kernel set."""
+    class FakeCuda(torch.Tensor):
+        @property
+        def is_cuda(self):
+            return True
+    for D, msg in ((24, "D % 16"), (256, "D % 16"), (32, "no compiled gfx950 kernel")):
+        t = torch.zeros(1, 1, 8, D).as_subclass(FakeCuda)
+        with pytest.raises(fa.FlashAttnArgumentError, match=msg):
+            fa.check_args(t, t, t)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="cannot load HIP library"):
+        fa.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.dirname(fa.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "oracle/" not in text, f
+
+
+def test_shard_bounds_cover_units_exactly():
+    for units in (0, 1, 7, 16, 256, 2048, 2049):
+        for world in (1, 2, 3, 4, 8):
+            spans = [fdist.shard_bounds(units, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == units
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        fdist.shard_bounds(4, 4, 4)
+
+
+def test_local_shard_is_a_view():
+    t = torch.arange(2 * 3 * 4 * 8, dtype=torch.float32).reshape(2, 3, 4, 8)
+    s = fdist.local_shard(t, 1, 4)          # 6 units over 4 ranks: sizes 2,2,1,1
+    assert s.shape == (2, 1, 4, 8)
+    assert s.data_ptr() == t.reshape(6, 1, 4, 8)[2:4].data_ptr()
+
+
+def test_flop_and_byte_model():
+    assert attn_flops(8, 32, 4096, 128, True) == pytest.approx(1.0995e12, rel=1e-4)
+    assert attn_flops(1, 32, 8192, 128, False) == pytest.approx(4 * 32 * 8192 ** 2 * 128)
+    assert attn_bytes(8, 32, 4096, 128) == pytest.approx(1073.7e6 + 4.19e6, rel=1e-3)
