@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
     }
 
-    // ---- K/V staging: thread -> (row, chunk) of the tile
+    // ---- K/V staging: thread -> (row, chunk) of the tile.  LDS: [K0][K1][V0][V1], TILE bytes each.
     unsigned g_koff[CPT], g_voff[CPT], l_koff[CPT], l_voff[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -182,35 +182,38 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         g_koff[i] = (unsigned)(row * p.k_ss * 2 + ch * 16);
         g_voff[i] = (unsigned)(row * p.v_ss * 2 + ch * 16);
         l_koff[i] = row * ROWB + k_swz<D>(row, ch) * 16;
-        l_voff[i] = TILE + row * ROWB + v_swz<D>(row, ch) * 16;
+        l_voff[i] = 2 * TILE + row * ROWB + v_swz<D>(row, ch) * 16;
     }
     const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * 2);
     const unsigned v_tile_stride = (unsigned)(kBN * p.v_ss * 2);
 
+    // rows past the end of the sequence fall outside the descriptor and read as zero
+    // (the host guarantees (S + 256) * row_stride_bytes < 2^31: no 32-bit wrap)
     u32x4 kreg[CPT], vreg[CPT];
-    auto load_tile = [&](int j) {
+    auto load_k = [&](int j) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            // rows past the end of the sequence fall outside the descriptor and read as zero
-            // (the host guarantees (S + 256) * row_stride_bytes < 2^31: no 32-bit wrap)
+        for (int i = 0; i < CPT; ++i)
             kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)j * k_tile_stride + g_koff[i], 0, 0);
-            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)j * v_tile_stride + g_voff[i], 0, 0);
-        }
     };
-    auto store_tile = [&](int buf) {
-        const unsigned base = lds_base + buf * (2 * TILE);
+    auto load_v = [&](int j) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            lds_write_b128(base + l_koff[i], kreg[i]);
-            lds_write_b128(base + l_voff[i], vreg[i]);
-        }
+        for (int i = 0; i < CPT; ++i)
+            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)j * v_tile_stride + g_voff[i], 0, 0);
+    };
+    auto store_k = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) lds_write_b128(lds_base + buf * TILE + l_koff[i], kreg[i]);
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) lds_write_b128(lds_base + buf * TILE + l_voff[i], vreg[i]);
     };
 
     // ---- LDS read addresses
     // K fragment (A operand): lane (r,hh) reads K[kb*32 + r][16 ks + 8 hh + 0..7] = chunk 2ks+hh of row
     unsigned ka[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ka[ks] = r * ROWB + k_swz<D>(r, 2 * ks + hh) * 16;   // + kb*32*ROWB
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = lds_base + r * ROWB + k_swz<D>(r, 2 * ks + hh) * 16;   // + kb*32*ROWB
     // V^T fragment (A operand of O^T = V^T P^T): 4x16 transposed blocks.
     //   16-lane group g16 (0/1) covers head_dim columns 16*g16..+15 of the 32-wide block,
     //   lane i of the group supplies row (i>>2), columns 4*(i&3)..+3; lane half hh adds 4 keys.
@@ -222,9 +225,29 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const int ch = 4 * db + 2 * g16 + (pp >> 1);
-            va[db] = TILE + row * ROWB + v_swz<D>(row, ch) * 16 + 8 * (pp & 1);
+            va[db] = lds_base + 2 * TILE + row * ROWB + v_swz<D>(row, ch) * 16 + 8 * (pp & 1);
         }
     }
+
+    // K fragments are read in groups of 4 k-steps, one group ahead of the MFMAs that use them.
+    constexpr int GPB = KS / 4;           // groups per 32-key block
+    constexpr int NG = 2 * GPB;           // groups per tile
+    u32x4 kf[2][4];
+    auto read_kgroup = [&](u32x4 (&dst)[4], unsigned koff, int g) {
+        const int kb = g / GPB, ks0 = (g % GPB) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = lds_read_b128(ka[ks0 + i] + koff + kb * 32 * ROWB);
+    };
+    // V^T fragments of one 16-key k-step (DB blocks of 32 head_dim columns)
+    u32x4 vf[2][DB];
+    auto read_vstep = [&](u32x4 (&dst)[DB], unsigned voff, int s) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            u32x2 lo = lds_read_tr16_b64(va[db] + voff + (16 * s) * ROWB);
+            u32x2 hi = lds_read_tr16_b64(va[db] + voff + (16 * s + 8) * ROWB);
+            dst[db] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+    };
 
     f32x16 o_acc[DB];
 #pragma unroll
@@ -235,34 +258,52 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     float l_part = 0.f;        // this lane's share of the row sum (lanes r and r+32 are combined at the end)
     const float c = p.scale_log2;
 
-    // ---- prologue: tile 0 -> LDS buffer 0, tile 1 in flight
-    load_tile(0);
-    store_tile(0);
-    load_tile(1);
+    // ---- prologue: tile 0 -> LDS buffers 0, tile 1 in flight, first K fragments in registers
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    load_k(1);
+    load_v(1);
     __syncthreads();
+    read_kgroup(kf[0], 0, 0);
 
+    // One barrier per tile.  Buffer life times (b = j & 1):
+    //   K[b]: written in iteration j-1 before barrier(j-1); read in QK(j) (first group already during PV(j-1),
+    //         i.e. after barrier(j-1)); overwritten in iteration j+1 before barrier(j+1), after barrier(j).
+    //   V[b]: written in iteration j-1 after barrier(j-1); read in PV(j) after barrier(j); overwritten in
+    //         iteration j+1 after barrier(j+1).
     for (int j = 0; j < nt; ++j) {
-        const unsigned buf = lds_base + (j & 1) * (2 * TILE);
+        const unsigned koff = (j & 1) * TILE;
+        const unsigned voff = (j & 1) * TILE;
+        const unsigned koff_n = ((j + 1) & 1) * TILE;
         const bool active = j < my_nt;          // wave-uniform
         f32x16 s_acc[2];
         if (active) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s_acc[kb][i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    u32x4 kf = lds_read_b128(buf + ka[ks] + kb * 32 * ROWB);
-                    s_acc[kb] = T::mfma(kf, qf[ks], s_acc[kb]);
-                }
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) read_kgroup(kf[(g + 1) & 1], koff, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kb = g / GPB, ks0 = (g % GPB) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_acc[kb] = T::mfma(kf[g & 1][i], qf[ks0 + i], s_acc[kb]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // stage tile j+1 into the other buffer (its previous readers passed the last barrier),
-        // then put tile j+2 in flight.
-        store_tile((j + 1) & 1);
-        load_tile(j + 2);
+        // K tile j+1 -> LDS (its buffer was last read in QK(j-1), before barrier(j-1)); K tile j+2 in flight
+        store_k((j + 1) & 1);
+        load_k(j + 2);
+        __syncthreads();                       // barrier(j)
+        // V tile j+1 -> LDS (its buffer was last read in PV(j-1), before barrier(j)); V tile j+2 in flight
+        store_v((j + 1) & 1);
+        load_v(j + 2);
 
         if (active) {
+            read_vstep(vf[0], voff, 0);
             const int k0 = j * kBN;
             const bool need_mask = (CAUSAL && (k0 + kBN - 1 > q0w)) || (k0 + kBN > S);
             if (need_mask) {
@@ -322,16 +363,12 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             // 16s + 8(jj>>2) + 4hh + (jj&3), which is exactly the order of the S^T accumulator registers.
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+                if (s + 1 < 4) read_vstep(vf[(s + 1) & 1], voff, s + 1);
+                else read_kgroup(kf[0], koff_n, 0);           // first K fragments of tile j+1
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    u32x2 lo = lds_read_tr16_b64(buf + va[db] + (16 * s) * ROWB);
-                    u32x2 hi = lds_read_tr16_b64(buf + va[db] + (16 * s + 8) * ROWB);
-                    u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
-                    o_acc[db] = T::mfma(vf, pf[s], o_acc[db]);
-                }
+                for (int db = 0; db < DB; ++db) o_acc[db] = T::mfma(vf[s & 1][db], pf[s], o_acc[db]);
             }
         }
-        __syncthreads();
     }
 
     // ---- epilogue: combine the two lane halves' row sums, normalise, store O (and LSE)

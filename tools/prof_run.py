@@ -1,0 +1,26 @@
+"""Tiny driver for rocprofv3: N launches of the fused forward at a named workload."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+from flash_attention_impls_amd import flash_attn
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=8)
+ap.add_argument("--H", type=int, default=32)
+ap.add_argument("--S", type=int, default=4096)
+ap.add_argument("--D", type=int, default=128)
+ap.add_argument("--causal", type=int, default=1)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
+torch.manual_seed(0)
+q, k, v = (torch.randn(a.B, a.H, a.S, a.D, device="cuda").to(dt) for _ in range(3))
+for _ in range(a.iters):
+    o = flash_attn(q, k, v, bool(a.causal))
+torch.cuda.synchronize()
+print("done", float(o.float().abs().mean()))
