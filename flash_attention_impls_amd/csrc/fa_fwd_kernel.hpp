@@ -5,7 +5,8 @@
 //   flash_attn_cutlass_kernel<D> code/cutlass_cuda_fa1/run/flash_attn_cutlass.cu:346-453
 //
 // Structure (one workgroup = 8 wave64 = one 256-row query block of one (batch, head)):
-//   * each wave owns 32 query rows; the workgroup walks 64-key K/V tiles.
+//   * each wave owns 32 query rows; the workgroup walks 64-key K/V tiles, each wave processes
+//     them as two 32-key half-tiles ("blocks").
 //   * S^T = K . Q^T  with v_mfma_f32_32x32x16 (K fragment = A operand from LDS via
 //     ds_read_b128, Q fragment = B operand, resident in VGPRs).  With this orientation the
 //     accumulator holds, per lane, 16 keys x ONE query (query = lane & 31), so the online
@@ -13,16 +14,22 @@
 //   * O^T += V^T . P^T : the S^T accumulator, converted to 16-bit pairs, IS the B operand
 //     (no LDS round trip for P); V^T fragments come from the row-major V tile in LDS through
 //     ds_read_b64_tr_b16 (hardware transpose read).
+//   * software pipeline over blocks n: one straight-line basic block issues the MFMAs of
+//     S(n) and of PV(n-2) with the softmax VALU work of block n-1 in between, so the
+//     exp/convert work hides in the MFMA shadows instead of serialising with them.
+//     The exponentials are computed speculatively against the current running max; a rare
+//     wave-uniform fix-up (some row's max grew by more than RESCALE_THR, in log2 units)
+//     rescales O and l and recomputes that block's P.
 //   * K/V tiles: global -> VGPR (buffer_load_dwordx4, coalesced along head_dim, OOB rows
 //     read as zero) -> LDS (ds_write_b128, XOR-swizzled so both the row reads of K and the
-//     transposed reads of V are bank-conflict free), double buffered, one barrier per tile;
+//     transposed reads of V are bank-conflict free), 3-deep ring, ONE barrier per 64-key tile;
 //     the loads for tile j+2 are in flight while tile j is computed.
-//   * exp2 with scale*log2(e) folded in, deferred 1/l normalisation, lazy O rescale
-//     (only when some row's max grew by more than RESCALE_THR in log2 units),
-//     causal tile skipping + diagonal-only masking, LSE output.
+//   * exp2 with scale*log2(e) folded in, deferred 1/l normalisation, causal block skipping +
+//     diagonal-only masking, LSE output.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fa {
 
@@ -52,7 +59,12 @@ struct FwdParams {
 
 template <class To, class From> __device__ __forceinline__ To bitcast(From f) { return __builtin_bit_cast(To, f); }
 
+// kPBias : log2 offset added to the softmax reference so that P = exp2(score - ref) starts at 2^-kPBias and has
+//          room to grow while the reference stays fixed (fp16 P saturates at 65504; bf16 has the fp32 range).
+// kPLimit: a per-lane block sum of P at or above this value flags the fixed-reference pass as unusable.
 struct TypeBF16 {
+    static constexpr float kPBias = 0.0f;
+    static constexpr float kPLimit = 1.0e30f;
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8>(a), bitcast<bf16x8>(b), c, 0, 0, 0);
     }
@@ -62,6 +74,8 @@ struct TypeBF16 {
     }
 };
 struct TypeF16 {
+    static constexpr float kPBias = 6.0f;
+    static constexpr float kPLimit = 60000.0f;
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a), bitcast<f16x8>(b), c, 0, 0, 0);
     }
@@ -76,7 +90,8 @@ constexpr int kBN = 64;           // keys per tile
 constexpr int kThreads = 512;
 constexpr float kRescaleThr = 8.0f;   // log2 units; 0 = rescale whenever any row max grows
 
-template <int D> constexpr int lds_bytes() { return 2 /*buffers*/ * 2 /*K,V*/ * kBN * D * 2; }
+constexpr int kStages = 3;       // LDS ring depth (tiles) for K and for V
+template <int D> constexpr int lds_bytes() { return kStages * 2 /*K,V*/ * kBN * D * 2; }
 
 typedef __attribute__((address_space(3))) char lds_char;
 
@@ -89,6 +104,28 @@ __device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
 __device__ __forceinline__ u32x2 lds_read_tr16_b64(unsigned addr) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(addr));
     return bitcast<u32x2>(t);
+}
+
+// LDS-DMA: 64 lanes x 16 bytes from per-lane buffer offsets `voff` to LDS [lds_addr, lds_addr + 1024)
+// (wave-uniform destination, lane l lands at lds_addr + 16 l).  Issued through inline asm so that hipcc does
+// not count it: its own bookkeeping would drain every DMA (s_waitcnt vmcnt(0)) in front of the next ds_read.
+// The kernel waits for its DMAs itself (dma_wait) before the barrier that publishes a tile.
+// M0 (LDS base of the transfer) is compiler-reserved: written in the same statement that uses it.
+__device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// buffer descriptor words for raw (stride 0) access to [base, base + bytes), built from wave-uniform values
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
 }
 
 // 16-byte-chunk swizzles of the LDS tiles (row = key index inside the tile).
@@ -104,6 +141,13 @@ template <int D> __device__ __forceinline__ int v_swz(int row, int ch) {
     if constexpr (D == 128) return ch ^ ((row & 3) << 2);
     else return ch ^ (((row >> 1) & 1) << 2);
 }
+
+template <int V> using IC = std::integral_constant<int, V>;
+
+struct SmState {
+    f32x16 sv;        // (masked) scores of one 32-key block
+    float rs;         // this lane's partial row sum
+};
 
 template <class T, int D, bool CAUSAL>
 __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
@@ -173,47 +217,43 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
     }
 
-    // ---- K/V staging: thread -> (row, chunk) of the tile.  LDS: [K0][K1][V0][V1], TILE bytes each.
-    unsigned g_koff[CPT], g_voff[CPT], l_koff[CPT], l_voff[CPT];
+    // ---- K/V staging by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR round trip.
+    // LDS: K ring [kStages][TILE], then V ring.  One wave-instruction writes a 1-KiB piece linearly
+    // (M0 base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE address: the lane that
+    // lands on LDS chunk position c' of row `row` fetches global chunk  c' ^ f(row)  of that row.
+    // Rows past the end of the sequence fall outside the descriptor and are written as zeros
+    // (the host guarantees (S + 256) * row_stride_bytes < 2^31: no 32-bit wrap).
+    constexpr int VBASE = kStages * TILE;
+    constexpr int PIECE = 1024;
+    unsigned g_koff[CPT], g_voff[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int c = tid + kThreads * i;
-        const int row = c / CH, ch = c % CH;
-        g_koff[i] = (unsigned)(row * p.k_ss * 2 + ch * 16);
-        g_voff[i] = (unsigned)(row * p.v_ss * 2 + ch * 16);
-        l_koff[i] = row * ROWB + k_swz<D>(row, ch) * 16;
-        l_voff[i] = 2 * TILE + row * ROWB + v_swz<D>(row, ch) * 16;
+        const int byte = (wave * CPT + i) * PIECE + lane * 16;
+        const int row = byte / ROWB, chp = (byte % ROWB) / 16;
+        g_koff[i] = (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16);
+        g_voff[i] = (unsigned)(row * p.v_ss * 2 + v_swz<D>(row, chp) * 16);
     }
     const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * 2);
     const unsigned v_tile_stride = (unsigned)(kBN * p.v_ss * 2);
-
-    // rows past the end of the sequence fall outside the descriptor and read as zero
-    // (the host guarantees (S + 256) * row_stride_bytes < 2^31: no 32-bit wrap)
-    u32x4 kreg[CPT], vreg[CPT];
-    auto load_k = [&](int j) {
+    const unsigned piece_base = lds_base + wave * CPT * PIECE;       // wave-uniform
+    const u32x4 rk_w = make_rsrc(kh, k_bytes);
+    const u32x4 rv_w = make_rsrc(vh, v_bytes);
+    auto dma_k = [&](int j, unsigned stage_off) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
-            kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)j * k_tile_stride + g_koff[i], 0, 0);
+            dma16(rk_w, __builtin_amdgcn_readfirstlane(piece_base + stage_off + i * PIECE), (unsigned)j * k_tile_stride + g_koff[i]);
     };
-    auto load_v = [&](int j) {
+    auto dma_v = [&](int j, unsigned stage_off) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
-            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)j * v_tile_stride + g_voff[i], 0, 0);
-    };
-    auto store_k = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) lds_write_b128(lds_base + buf * TILE + l_koff[i], kreg[i]);
-    };
-    auto store_v = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) lds_write_b128(lds_base + buf * TILE + l_voff[i], vreg[i]);
+            dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + stage_off + i * PIECE), (unsigned)j * v_tile_stride + g_voff[i]);
     };
 
-    // ---- LDS read addresses
-    // K fragment (A operand): lane (r,hh) reads K[kb*32 + r][16 ks + 8 hh + 0..7] = chunk 2ks+hh of row
+    // ---- LDS read addresses (they carry the ring-stage offset of the tile currently being read)
+    // K fragment (A operand): lane (r,hh) reads K[half*32 + r][16 ks + 8 hh + 0..7] = chunk 2ks+hh of row
     unsigned ka[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ka[ks] = lds_base + r * ROWB + k_swz<D>(r, 2 * ks + hh) * 16;   // + kb*32*ROWB
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = lds_base + r * ROWB + k_swz<D>(r, 2 * ks + hh) * 16;
     // V^T fragment (A operand of O^T = V^T P^T): 4x16 transposed blocks.
     //   16-lane group g16 (0/1) covers head_dim columns 16*g16..+15 of the 32-wide block,
     //   lane i of the group supplies row (i>>2), columns 4*(i&3)..+3; lane half hh adds 4 keys.
@@ -225,27 +265,28 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const int ch = 4 * db + 2 * g16 + (pp >> 1);
-            va[db] = lds_base + 2 * TILE + row * ROWB + v_swz<D>(row, ch) * 16 + 8 * (pp & 1);
+            va[db] = lds_base + VBASE + row * ROWB + v_swz<D>(row, ch) * 16 + 8 * (pp & 1);
         }
     }
 
-    // K fragments are read in groups of 4 k-steps, one group ahead of the MFMAs that use them.
-    constexpr int GPB = KS / 4;           // groups per 32-key block
-    constexpr int NG = 2 * GPB;           // groups per tile
-    u32x4 kf[2][4];
-    auto read_kgroup = [&](u32x4 (&dst)[4], unsigned koff, int g) {
-        const int kb = g / GPB, ks0 = (g % GPB) * 4;
+    // K fragments are read in groups of 4 k-steps; V^T fragments per 16-key k-step (DB blocks).
+    // One register set each: a group is re-read right after the MFMAs that consumed the previous one
+    // were issued, and lands while the MFMAs of the other product run.
+    constexpr int GPB = KS / 4;           // K groups per 32-key block (2 @ D=128, 1 @ D=64)
+    u32x4 kf[4];
+    u32x4 vf[DB];
+    auto read_kgroup = [&] __device__ (auto half_c, auto g_c) {
+        constexpr int half = decltype(half_c)::value, g = decltype(g_c)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = lds_read_b128(ka[ks0 + i] + koff + kb * 32 * ROWB);
+        for (int i = 0; i < 4; ++i) kf[i] = lds_read_b128(ka[4 * g + i] + half * 32 * ROWB);
     };
-    // V^T fragments of one 16-key k-step (DB blocks of 32 head_dim columns)
-    u32x4 vf[2][DB];
-    auto read_vstep = [&](u32x4 (&dst)[DB], unsigned voff, int s) {
+    auto read_vstep = [&] __device__ (auto s_c) {
+        constexpr int s = decltype(s_c)::value;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            u32x2 lo = lds_read_tr16_b64(va[db] + voff + (16 * s) * ROWB);
-            u32x2 hi = lds_read_tr16_b64(va[db] + voff + (16 * s + 8) * ROWB);
-            dst[db] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            u32x2 lo = lds_read_tr16_b64(va[db] + (16 * s) * ROWB);
+            u32x2 hi = lds_read_tr16_b64(va[db] + (16 * s + 8) * ROWB);
+            vf[db] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
 
@@ -254,119 +295,295 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o_acc[db][i] = 0.f;
-    float m_c = -INFINITY;     // running max, already multiplied by scale*log2(e)
+    float m_c = -INFINITY;     // running max reference, already multiplied by scale*log2(e)
     float l_part = 0.f;        // this lane's share of the row sum (lanes r and r+32 are combined at the end)
     const float c = p.scale_log2;
 
-    // ---- prologue: tile 0 -> LDS buffers 0, tile 1 in flight, first K fragments in registers
-    load_k(0);
-    load_v(0);
-    store_k(0);
-    store_v(0);
-    load_k(1);
-    load_v(1);
-    __syncthreads();
-    read_kgroup(kf[0], 0, 0);
+    f32x16 s_acc[2];           // S^T of block n (being produced) and n-1 (being consumed)
+    u32x4 pf[2][2];            // P^T fragments (2 k-steps of 16 keys) of block n-1 (produced) and n-2 (consumed)
 
-    // One barrier per tile.  Buffer life times (b = j & 1):
-    //   K[b]: written in iteration j-1 before barrier(j-1); read in QK(j) (first group already during PV(j-1),
-    //         i.e. after barrier(j-1)); overwritten in iteration j+1 before barrier(j+1), after barrier(j).
-    //   V[b]: written in iteration j-1 after barrier(j-1); read in PV(j) after barrier(j); overwritten in
-    //         iteration j+1 after barrier(j+1).
-    for (int j = 0; j < nt; ++j) {
-        const unsigned koff = (j & 1) * TILE;
-        const unsigned voff = (j & 1) * TILE;
-        const unsigned koff_n = ((j + 1) & 1) * TILE;
-        const bool active = j < my_nt;          // wave-uniform
-        f32x16 s_acc[2];
-        if (active) {
+    // ---- softmax of one 32-key block, in pieces that the pipeline block interleaves with its MFMA groups.
+    // FAST PATH: the softmax reference m_c of a row is fixed once, from the row maximum of key block 0
+    // (+ kPBias), and never raised afterwards: P = exp2(score*c - m_c) may exceed 1 (bf16 / fp32 have the
+    // range), O and l simply accumulate at that scale, and no running max / rescale work exists in the loop.
+    // If a block sum ever reaches kPLimit (scores far above the first block's), `p_peak` records it and the
+    // whole workgroup redoes its query block with the exact online-softmax loop further below.
+    float p_peak = 0.f;
+    auto sm_begin = [&] __device__ (auto mask_c, auto first_c, const f32x16& s_in, int key0, SmState& st) {
+        constexpr bool MASK = decltype(mask_c)::value, FIRST = decltype(first_c)::value;
+        st.sv = s_in;
+        st.rs = 0.f;
+        if constexpr (MASK) {
+            const int qrow = q0w + r;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s_acc[kb][i] = 0.f;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g + 1 < NG) read_kgroup(kf[(g + 1) & 1], koff, g + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const int kb = g / GPB, ks0 = (g % GPB) * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s_acc[kb] = T::mfma(kf[g & 1][i], qf[ks0 + i], s_acc[kb]);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 16; ++i) {
+                const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const bool dead = (key >= S) || (CAUSAL && key > qrow);
+                if (dead) st.sv[i] = -INFINITY;
             }
         }
-        // K tile j+1 -> LDS (its buffer was last read in QK(j-1), before barrier(j-1)); K tile j+2 in flight
-        store_k((j + 1) & 1);
-        load_k(j + 2);
-        __syncthreads();                       // barrier(j)
-        // V tile j+1 -> LDS (its buffer was last read in PV(j-1), before barrier(j)); V tile j+2 in flight
-        store_v((j + 1) & 1);
-        load_v(j + 2);
-
-        if (active) {
-            read_vstep(vf[0], voff, 0);
-            const int k0 = j * kBN;
-            const bool need_mask = (CAUSAL && (k0 + kBN - 1 > q0w)) || (k0 + kBN > S);
-            if (need_mask) {
-                const int qrow = q0w + r;
+        if constexpr (FIRST) {            // key block 0 fixes the reference
+            float mx = fmaxf(st.sv[0], st.sv[1]);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+            for (int i = 2; i < 16; ++i) mx = fmaxf(mx, st.sv[i]);
+            auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(mx), bitcast<unsigned>(mx), false, false);
+            mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
+            m_c = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, T::kPBias);
+        }
+    };
+    // exponentials of scores [i0, i1) (i0, i1 even) against reference m_ref (already scaled); each pair is
+    // converted to 16 bits at once and dropped into its word of the P^T fragments
+    auto sm_exp = [&] __device__ (SmState& st, u32x4 (&pw)[2], auto i0_c, auto i1_c, float m_ref) {
+        constexpr int i0 = decltype(i0_c)::value, i1 = decltype(i1_c)::value;
+#pragma unroll
+        for (int i = i0; i < i1; i += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st.sv[i], c, -m_ref));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st.sv[i + 1], c, -m_ref));
+            st.rs += p0;
+            st.rs += p1;
+            pw[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
+        }
+    };
+    auto sm_end = [&] __device__ (SmState& st) {
+        l_part += st.rs;
+        p_peak = fmaxf(p_peak, st.rs);
+    };
+
+    // One pipeline block n (HALF = n & 1 selects the 32-key half of the 64-key tiles):
+    //   MFMA: PV(n-2) (V tile j-1, rows 32*HALF..) and S(n) (K tile j, rows 32*HALF..), j = n >> 1
+    //   VALU: softmax(n-1)
+    //   LDS : each fragment group is re-read right after the MFMAs that consumed it were issued and lands
+    //         while the other product's MFMAs run; the last two reads prefetch the next block's first groups.
+    //         Odd blocks advance the address registers to the next tiles (dk/dv = ring-stage byte deltas).
+    // The block is cut into regions (one MFMA group + a slice of the softmax each) by scheduling fences, so that
+    // the compiler interleaves inside a region but keeps the fragment reads one group ahead.
+    auto mfma_pv = [&] __device__ (auto half_c, auto kstep_c) {
+        constexpr int HALFv = decltype(half_c)::value, kstep = decltype(kstep_c)::value;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o_acc[db] = T::mfma(vf[db], pf[HALFv][kstep], o_acc[db]);
+    };
+    auto advance = [&](int dk, int dv) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka[ks] += dk;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) va[db] += dv;
+    };
+    auto block = [&] __device__ (auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, int n, int dk, int dv) {
+        constexpr int HALF = decltype(half_c)::value;
+        constexpr bool DO_S = decltype(do_s_c)::value, DO_SM = decltype(do_sm_c)::value, DO_PV = decltype(do_pv_c)::value;
+        f32x16& sw_ = s_acc[HALF];            // S(n)
+        const f32x16& sr_ = s_acc[HALF ^ 1];  // S(n-1)
+        u32x4 (&pw)[2] = pf[HALF ^ 1];        // P(n-1)
+        SmState st;
+        // ---- region 0: PV k-step 0 | softmax head
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DO_PV) {
+            mfma_pv(IC<HALF>{}, IC<0>{});
+            read_vstep(IC<2 * HALF + 1>{});
+        }
+        if constexpr (DO_SM) {
+            sm_begin(mask_c, first_c, sr_, (n - 1) * 32, st);
+            sm_exp(st, pw, IC<0>{}, IC<4>{}, m_c);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region 1: S group 0 | exponentials
+        if constexpr (DO_S) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sw_[i] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw_ = T::mfma(kf[i], qf[i], sw_);
+        }
+        if constexpr (GPB == 2) {
+            if constexpr (DO_S) read_kgroup(IC<HALF>{}, IC<1>{});
+            if constexpr (DO_SM) sm_exp(st, pw, IC<4>{}, IC<8>{}, m_c);
+        } else {
+            if constexpr (HALF == 1) advance(dk, dv);
+            read_kgroup(IC<HALF ^ 1>{}, IC<0>{});             // next block's K fragments
+            if constexpr (DO_SM) sm_exp(st, pw, IC<4>{}, IC<12>{}, m_c);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region 2: PV k-step 1 | exponentials
+        if constexpr (DO_PV) mfma_pv(IC<HALF>{}, IC<1>{});
+        if constexpr (GPB == 2) {
+            if constexpr (HALF == 1) advance(dk, dv);
+            read_vstep(IC<2 * (HALF ^ 1)>{});                 // next block's first V^T fragments
+            if constexpr (DO_SM) sm_exp(st, pw, IC<8>{}, IC<12>{}, m_c);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- region 3: S group 1 | exponentials
+            if constexpr (DO_S) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sw_ = T::mfma(kf[i], qf[4 + i], sw_);
+            }
+            read_kgroup(IC<HALF ^ 1>{}, IC<0>{});             // next block's first K fragments
+        } else {
+            read_vstep(IC<2 * (HALF ^ 1)>{});
+        }
+        if constexpr (DO_SM) {
+            sm_exp(st, pw, IC<12>{}, IC<16>{}, m_c);
+            sm_end(st);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    typedef std::true_type Y;
+    typedef std::false_type N;
+    typedef std::integral_constant<int, 0> half0_t;
+    typedef std::integral_constant<int, 1> half1_t;
+
+    // ---- prologue: K(0), K(1), V(0) by DMA; first K fragments in registers
+    dma_k(0, 0);
+    dma_k(1, TILE);
+    dma_v(0, 0);
+    dma_wait();                 // this wave's pieces have landed ...
+    __syncthreads();            // ... and every wave's are visible
+
+    // Iteration j: block 2j | barrier(j) | DMA K(j+2), V(j+1) | block 2j+1.      (stage of tile t = t % 3)
+    //   reads : K(j), V(j-1)                        -- landed before and published by barrier(j-1)
+    //   block 2j+1 prefetches from K(j+1), V(j)     -- DMA issued in iteration j-1, published by barrier(j)
+    //   DMA K(j+2) overwrites K(j-1), DMA V(j+1) overwrites V(j-2): last read in block 2j-1, before barrier(j).
+    // Every wave executes barrier(j) and its share of the DMA for j = 0..nt-1; the compute of a wave covers
+    // its own NT = my_nt tiles: fill (iteration 0), steady loops, drain (iteration NT), then a DMA/barrier tail.
+    int stage_k = 0;                               // ring stage of tile j
+    int dk = 0, dv = 0;                            // address deltas used by the odd block of iteration j
+    auto begin_iter = [&](int j) {
+        const int st1 = (stage_k == kStages - 1) ? 0 : stage_k + 1;
+        dk = (st1 - stage_k) * TILE;                                           // K(j) -> K(j+1)
+        dv = (j == 0) ? 0 : ((stage_k == 0) ? -(kStages - 1) * TILE : TILE);   // V(j-1) -> V(j)
+    };
+    auto sync_and_stage = [&](int j) {             // barrier(j) + DMA of K(j+2), V(j+1)
+        const int st1 = (stage_k == kStages - 1) ? 0 : stage_k + 1;
+        const int st2 = (st1 == kStages - 1) ? 0 : st1 + 1;
+        dma_wait();                                // the DMA issued one iteration ago has landed ...
+        __syncthreads();                           // ... and is published; last iteration's reads are done
+        dma_k(j + 2, st2 * TILE);
+        dma_v(j + 1, st1 * TILE);
+    };
+    auto end_iter = [&]() { stage_k = (stage_k == kStages - 1) ? 0 : stage_k + 1; };
+
+    const int NT = my_nt;                          // 64-key tiles this wave computes on
+    // first block whose softmax needs the mask (causal diagonal or ragged end)
+    const int mb = min(CAUSAL ? (q0w >> 5) : 0x7fffffff, S >> 5);
+    const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
+    int j = 0;
+    if (NT > 0) {
+        read_kgroup(IC<0>{}, IC<0>{});
+        // iteration 0 (pipeline fill); softmax(0) fixes the reference
+        begin_iter(0);
+        block(half0_t{}, Y{}, N{}, N{}, N{}, N{}, 0, 0, 0);
+        sync_and_stage(0);
+        block(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, 1, dk, dv);
+        end_iter();
+        j = 1;
+        const int ja = min(jm, NT);
+        for (; j < ja; ++j) {                      // steady state, no masking
+            begin_iter(j);
+            block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, 2 * j, 0, 0);
+            sync_and_stage(j);
+            block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, 2 * j + 1, dk, dv);
+            end_iter();
+        }
+        for (; j < NT; ++j) {                      // steady state with masking (diagonal / ragged tiles)
+            begin_iter(j);
+            block(half0_t{}, Y{}, Y{}, Y{}, Y{}, N{}, 2 * j, 0, 0);
+            sync_and_stage(j);
+            block(half1_t{}, Y{}, Y{}, Y{}, Y{}, N{}, 2 * j + 1, dk, dv);
+            end_iter();
+        }
+        // iteration NT (pipeline drain)
+        begin_iter(j);
+        block(half0_t{}, N{}, Y{}, Y{}, Y{}, N{}, 2 * j, 0, 0);
+        if (j < nt) sync_and_stage(j);
+        block(half1_t{}, N{}, N{}, Y{}, N{}, N{}, 2 * j + 1, dk, dv);
+        end_iter();
+        ++j;
+    }
+    for (; j < nt; ++j) {                          // remaining tiles of the workgroup: staging duty only
+        sync_and_stage(j);
+        end_iter();
+    }
+
+    // ---- exact fallback (rare): some row's scores rose too far above its first-block reference.
+    // The whole workgroup redoes its query block with a plain per-tile online softmax (running max, rescale).
+    if (__syncthreads_or(!(p_peak < T::kPLimit))) {
+        constexpr int KO = 0, VO = 2 * TILE;                  // two stages each: K at KO, V at VO
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o_acc[db][i] = 0.f;
+        m_c = -INFINITY;
+        l_part = 0.f;
+        unsigned ka2[KS], va2[DB];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ka2[ks] = lds_base + KO + r * ROWB + k_swz<D>(r, 2 * ks + hh) * 16;
+        {
+            const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+            const int qq = i16 >> 2, pp = i16 & 3;
+            const int row = 4 * hh + qq;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                va2[db] = lds_base + VO + row * ROWB + v_swz<D>(row, 4 * db + 2 * g16 + (pp >> 1)) * 16 + 8 * (pp & 1);
+        }
+        auto dma2 = [&](int jj) {
+            const unsigned st = (jj & 1) * TILE;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                dma16(rk_w, __builtin_amdgcn_readfirstlane(piece_base + KO + st + i * PIECE), (unsigned)jj * k_tile_stride + g_koff[i]);
+                dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VO + st + i * PIECE), (unsigned)jj * v_tile_stride + g_voff[i]);
+            }
+        };
+        dma2(0);
+        for (int jj = 0; jj < nt; ++jj) {
+            dma_wait();
+            __syncthreads();                   // tile jj landed and is visible; tile jj-1's stage is free
+            dma2(jj + 1);
+            if (jj < my_nt) {
+                const unsigned st = (jj & 1) * TILE;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f32x16 sx;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sx[i] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        sx = T::mfma(lds_read_b128(ka2[ks] + st + half * 32 * ROWB), qf[ks], sx);
+                    const int qrow = q0w + r, key0 = jj * kBN + half * 32;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int key = k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        const bool dead = (key >= S) || (CAUSAL && key > qrow);
-                        if (dead) s_acc[kb][i] = -INFINITY;
+                        const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        if ((key >= S) || (CAUSAL && key > qrow)) sx[i] = -INFINITY;
                     }
-            }
-            // row max over this lane's 32 keys, then with lane ^ 32
-            float mx = s_acc[0][0];
+                    float mx = fmaxf(sx[0], sx[1]);
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s_acc[0][i]);
+                    for (int i = 2; i < 16; ++i) mx = fmaxf(mx, sx[i]);
+                    auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(mx), bitcast<unsigned>(mx), false, false);
+                    mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
+                    const float m_new = fmaxf(m_c, mx * c);
+                    const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_c - m_new);   // m_c = -inf -> 0
+                    l_part *= alpha;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s_acc[1][i]);
-            {
-                auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(mx), bitcast<unsigned>(mx), false, false);
-                mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
-            }
-            const float mx_c = mx * c;
-            // lazy rescale: only when some row's max grew by more than the threshold
-            if (__builtin_amdgcn_ballot_w64(mx_c - m_c > kRescaleThr) != 0) {   // NaN (-inf - -inf) compares false
-                const float m_new = fmaxf(m_c, mx_c);
-                const float alpha = __builtin_amdgcn_exp2f(m_c - m_new);     // m_c = -inf -> 0
-                l_part *= alpha;
+                    for (int db = 0; db < DB; ++db)
 #pragma unroll
-                for (int db = 0; db < DB; ++db)
+                        for (int i = 0; i < 16; ++i) o_acc[db][i] *= alpha;
+                    m_c = m_new;
+                    const float m_sub = (m_c == -INFINITY) ? 0.f : m_c;       // row fully masked so far
+                    u32x4 px[2];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) o_acc[db][i] *= alpha;
-                m_c = m_new;
-            }
-            const float m_sub = (m_c == -INFINITY) ? 0.f : m_c;   // fully masked so far: exp2(-inf - 0) = 0
-            u32x4 pf[4];
-            float rs = 0.f;
+                    for (int i = 0; i < 16; i += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[i], c, -m_sub));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[i + 1], c, -m_sub));
+                        l_part += p0 + p1;
+                        px[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
+                    }
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                float pv[16];
+                    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    pv[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][i], c, -m_sub));
-                    rs += pv[i];
+                        for (int db = 0; db < DB; ++db) {
+                            const int sidx = 2 * half + s2;
+                            u32x2 lo = lds_read_tr16_b64(va2[db] + st + (16 * sidx) * ROWB);
+                            u32x2 hi = lds_read_tr16_b64(va2[db] + st + (16 * sidx + 8) * ROWB);
+                            o_acc[db] = T::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, px[s2], o_acc[db]);
+                        }
                 }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    u32x4 f;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) f[w] = T::pack2(pv[8 * s2 + 2 * w], pv[8 * s2 + 2 * w + 1]);
-                    pf[kb * 2 + s2] = f;
-                }
-            }
-            l_part += rs;
-            // O^T += V^T P^T.  k-step s covers keys 16s..16s+15 of the tile in the permuted order
-            // 16s + 8(jj>>2) + 4hh + (jj&3), which is exactly the order of the S^T accumulator registers.
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s + 1 < 4) read_vstep(vf[(s + 1) & 1], voff, s + 1);
-                else read_kgroup(kf[0], koff_n, 0);           // first K fragments of tile j+1
-#pragma unroll
-                for (int db = 0; db < DB; ++db) o_acc[db] = T::mfma(vf[s & 1][db], pf[s], o_acc[db]);
             }
         }
     }
