@@ -90,7 +90,7 @@ constexpr int kBN = 64;           // keys per tile
 constexpr int kThreads = 512;
 constexpr float kRescaleThr = 8.0f;   // log2 units; 0 = rescale whenever any row max grows
 
-constexpr int kStages = 3;       // LDS ring depth (tiles) for K and for V
+constexpr int kStages = 4;       // LDS ring depth (tiles) for K and for V (a power of two)
 template <int D> constexpr int lds_bytes() { return kStages * 2 /*K,V*/ * kBN * D * 2; }
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -115,7 +115,8 @@ __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned vo
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                  :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
 }
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's DMA instructions are still in flight (vmcnt counts in issue order)
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 // buffer descriptor words for raw (stride 0) access to [base, base + bytes), built from wave-uniform values
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
@@ -277,11 +278,21 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     u32x4 vf[DB];
     auto read_kgroup = [&] __device__ (auto half_c, auto g_c) {
         constexpr int half = decltype(half_c)::value, g = decltype(g_c)::value;
+#if defined(FA_ABL_NOLDS)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(kf[i]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) kf[i] = lds_read_b128(ka[4 * g + i] + half * 32 * ROWB);
     };
     auto read_vstep = [&] __device__ (auto s_c) {
         constexpr int s = decltype(s_c)::value;
+#if defined(FA_ABL_NOLDS)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) asm volatile("" : "+v"(vf[db]));
+        return;
+#endif
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             u32x2 lo = lds_read_tr16_b64(va[db] + (16 * s) * ROWB);
@@ -337,10 +348,21 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         constexpr int i0 = decltype(i0_c)::value, i1 = decltype(i1_c)::value;
 #pragma unroll
         for (int i = i0; i < i1; i += 2) {
+#if defined(FA_ABL_NOVALU)    // timing-only ablation builds (wrong results): see tools/ab_bench.py
+            if (i == i0) { asm volatile("" : "+v"(st.sv)); pw[i >> 3][(i & 7) >> 1] = bitcast<unsigned>(st.sv[i]); }
+            continue;
+#endif
+#if defined(FA_ABL_NOEXP)
+            const float p0 = __builtin_fmaf(st.sv[i], c, -m_ref);
+            const float p1 = __builtin_fmaf(st.sv[i + 1], c, -m_ref);
+#else
             const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st.sv[i], c, -m_ref));
             const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st.sv[i + 1], c, -m_ref));
+#endif
+#if !defined(FA_ABL_NOSUM)
             st.rs += p0;
             st.rs += p1;
+#endif
             pw[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
         }
     };
@@ -430,35 +452,41 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     typedef std::integral_constant<int, 0> half0_t;
     typedef std::integral_constant<int, 1> half1_t;
 
-    // ---- prologue: K(0), K(1), V(0) by DMA; first K fragments in registers
+    // ---- prologue: K(0), V(0) must have landed before iteration 0; K(1), K(2), V(1) follow behind.
     dma_k(0, 0);
-    dma_k(1, TILE);
     dma_v(0, 0);
-    dma_wait();                 // this wave's pieces have landed ...
+    dma_k(1, TILE);
+    dma_k(2, 2 * TILE);
+    dma_v(1, TILE);
+    dma_wait<3 * CPT>();        // this wave's pieces of K(0), V(0) have landed ...
     __syncthreads();            // ... and every wave's are visible
 
-    // Iteration j: block 2j | barrier(j) | DMA K(j+2), V(j+1) | block 2j+1.      (stage of tile t = t % 3)
-    //   reads : K(j), V(j-1)                        -- landed before and published by barrier(j-1)
-    //   block 2j+1 prefetches from K(j+1), V(j)     -- DMA issued in iteration j-1, published by barrier(j)
-    //   DMA K(j+2) overwrites K(j-1), DMA V(j+1) overwrites V(j-2): last read in block 2j-1, before barrier(j).
+    // Iteration j: block 2j | wait, barrier(j) | DMA K(j+3), V(j+2) | block 2j+1.      (stage of tile t = t % 4)
+    //   reads : K(j), V(j-1)                        -- published by barrier(j-1) or earlier
+    //   block 2j+1 prefetches from K(j+1), V(j)     -- DMA issued in iteration j-2 (or the prologue); each wave
+    //                                                  waits for its own pieces (counted vmcnt, leaving the
+    //                                                  DMAs of iteration j-1 in flight) before barrier(j)
+    //   DMA K(j+3) overwrites K(j-1), DMA V(j+2) overwrites V(j-2): last read in block 2j-1, before barrier(j).
+    // The two-iteration flight time hides the HBM/L2 latency of a tile behind ~2 tiles of compute.
     // Every wave executes barrier(j) and its share of the DMA for j = 0..nt-1; the compute of a wave covers
     // its own NT = my_nt tiles: fill (iteration 0), steady loops, drain (iteration NT), then a DMA/barrier tail.
     int stage_k = 0;                               // ring stage of tile j
     int dk = 0, dv = 0;                            // address deltas used by the odd block of iteration j
     auto begin_iter = [&](int j) {
-        const int st1 = (stage_k == kStages - 1) ? 0 : stage_k + 1;
-        dk = (st1 - stage_k) * TILE;                                           // K(j) -> K(j+1)
+        dk = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;          // K(j) -> K(j+1)
         dv = (j == 0) ? 0 : ((stage_k == 0) ? -(kStages - 1) * TILE : TILE);   // V(j-1) -> V(j)
     };
-    auto sync_and_stage = [&](int j) {             // barrier(j) + DMA of K(j+2), V(j+1)
-        const int st1 = (stage_k == kStages - 1) ? 0 : stage_k + 1;
-        const int st2 = (st1 == kStages - 1) ? 0 : st1 + 1;
-        dma_wait();                                // the DMA issued one iteration ago has landed ...
+    auto sync_and_stage = [&](int j) {             // barrier(j) + DMA of K(j+3), V(j+2)
+        dma_wait<2 * CPT>();                       // everything but the previous iteration's DMA has landed ...
+#if !defined(FA_ABL_NOBARRIER)
         __syncthreads();                           // ... and is published; last iteration's reads are done
-        dma_k(j + 2, st2 * TILE);
-        dma_v(j + 1, st1 * TILE);
+#endif
+#if !defined(FA_ABL_NODMA)
+        dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
+        dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+#endif
     };
-    auto end_iter = [&]() { stage_k = (stage_k == kStages - 1) ? 0 : stage_k + 1; };
+    auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
 
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     // first block whose softmax needs the mask (causal diagonal or ragged end)
@@ -504,6 +532,7 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
 
     // ---- exact fallback (rare): some row's scores rose too far above its first-block reference.
     // The whole workgroup redoes its query block with a plain per-tile online softmax (running max, rescale).
+    dma_wait<0>();                                 // no DMA may still be writing LDS past this point
     if (__syncthreads_or(!(p_peak < T::kPLimit))) {
         constexpr int KO = 0, VO = 2 * TILE;                  // two stages each: K at KO, V at VO
 #pragma unroll
@@ -533,7 +562,7 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         };
         dma2(0);
         for (int jj = 0; jj < nt; ++jj) {
-            dma_wait();
+            dma_wait<0>();
             __syncthreads();                   // tile jj landed and is visible; tile jj-1's stage is free
             dma2(jj + 1);
             if (jj < my_nt) {
