@@ -16,7 +16,15 @@
 #include "../../include/fa_mi355.h"
 #include "fa_fwd_kernel.hpp"
 
+// 32-row query blocks per wave: 1 = 8 waves per workgroup (two per SIMD), 2 = 4 waves (one per SIMD, 512 registers)
+#ifndef FA_QB
+#define FA_QB 1
+#endif
+
 namespace {
+
+constexpr int kQB = FA_QB;
+constexpr int kThreads = fa::threads_per_wg<kQB>();
 
 thread_local char g_err[512] = "";
 
@@ -36,12 +44,12 @@ int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel<T, D, CAUSAL>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel<T, D, CAUSAL, kQB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((fa::fa_fwd_kernel<T, D, CAUSAL>), dim3(grid), dim3(fa::kThreads), lds, stream, p);
+    hipLaunchKernelGGL((fa::fa_fwd_kernel<T, D, CAUSAL, kQB>), dim3(grid), dim3(kThreads), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
@@ -53,11 +61,12 @@ int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
     return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
 }
 
-int grid_for(int B, int H, int S)
+int grid_for(int B, int H, int S, bool causal)
 {
     const long long bh = (long long)B * H;
     const long long nqb = (S + fa::kBM - 1) / fa::kBM;
-    const long long g = ((bh + 7) / 8) * 8 * nqb;     // heads padded to a multiple of 8 XCD groups
+    const long long per_head = causal ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
+    const long long g = ((bh + 7) / 8) * 8 * per_head;         // heads padded to a multiple of 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
 }
 
@@ -84,11 +93,10 @@ int fa_supported(int dtype, int head_dim)
 
 int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* grid, int* block, int* lds_bytes)
 {
-    (void)causal;
     if (!fa_supported(dtype, D)) return fail(FA_ERR_BAD_HEAD_DIM, "unsupported (dtype=%d, head_dim=%d)", dtype, D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape");
-    if (grid) *grid = grid_for(B, H, S);
-    if (block) *block = fa::kThreads;
+    if (grid) *grid = grid_for(B, H, S, causal != 0);
+    if (block) *block = kThreads;
     if (lds_bytes) *lds_bytes = (D == 128) ? fa::lds_bytes<128>() : fa::lds_bytes<64>();
     return FA_OK;
 }
@@ -140,7 +148,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     p.scale = scale;
     p.scale_log2 = scale * 1.4426950408889634f;
 
-    const int grid = grid_for(B, H, S);
+    const int grid = grid_for(B, H, S, causal != 0);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool c = causal != 0;

@@ -4,28 +4,27 @@
 //   _fwd_kernel                  code/triton_fa2/FA2-triton.py:25-93
 //   flash_attn_cutlass_kernel<D> code/cutlass_cuda_fa1/run/flash_attn_cutlass.cu:346-453
 //
-// Structure (one workgroup = 8 wave64 = one 256-row query block of one (batch, head)):
-//   * each wave owns 32 query rows; the workgroup walks 64-key K/V tiles, each wave processes
-//     them as two 32-key half-tiles ("blocks").
-//   * S^T = K . Q^T  with v_mfma_f32_32x32x16 (K fragment = A operand from LDS via
-//     ds_read_b128, Q fragment = B operand, resident in VGPRs).  With this orientation the
-//     accumulator holds, per lane, 16 keys x ONE query (query = lane & 31), so the online
-//     softmax (running max / sum) is lane-local plus one exchange with lane ^ 32.
-//   * O^T += V^T . P^T : the S^T accumulator, converted to 16-bit pairs, IS the B operand
-//     (no LDS round trip for P); V^T fragments come from the row-major V tile in LDS through
-//     ds_read_b64_tr_b16 (hardware transpose read).
-//   * software pipeline over blocks n: one straight-line basic block issues the MFMAs of
-//     S(n) and of PV(n-2) with the softmax VALU work of block n-1 in between, so the
-//     exp/convert work hides in the MFMA shadows instead of serialising with them.
-//     The exponentials are computed speculatively against the current running max; a rare
-//     wave-uniform fix-up (some row's max grew by more than RESCALE_THR, in log2 units)
-//     rescales O and l and recomputes that block's P.
-//   * K/V tiles: global -> VGPR (buffer_load_dwordx4, coalesced along head_dim, OOB rows
-//     read as zero) -> LDS (ds_write_b128, XOR-swizzled so both the row reads of K and the
-//     transposed reads of V are bank-conflict free), 3-deep ring, ONE barrier per 64-key tile;
-//     the loads for tile j+2 are in flight while tile j is computed.
-//   * exp2 with scale*log2(e) folded in, deferred 1/l normalisation, causal block skipping +
-//     diagonal-only masking, LSE output.
+// Structure (one workgroup = one 256-row query block of one (batch, head)):
+//   * template parameter QB = 32-row query blocks per wave: QB = 1 -> 8 waves (two per SIMD, <= 256 registers),
+//     QB = 2 -> 4 waves (one per SIMD, the whole 512-register file); with QB = 2 every K / V^T fragment read from
+//     LDS feeds two MFMAs.  The workgroup walks 64-key K/V tiles; each wave processes them as two 32-key
+//     half-tiles ("blocks").
+//   * S^T = K . Q^T  with v_mfma_f32_32x32x16 (K fragment = A operand from LDS via ds_read_b128, Q fragment =
+//     B operand, resident in registers).  With this orientation the accumulator holds, per lane, 16 keys x ONE
+//     query (query = lane & 31), so the softmax is lane-local (one exchange with lane ^ 32 for row statistics).
+//   * O^T += V^T . P^T : the S^T accumulator, converted to 16-bit pairs, IS the B operand (no LDS round trip
+//     for P); V^T fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16.
+//   * software pipeline over blocks n: one straight-line region sequence issues the MFMAs of S(n) and of PV(n-2)
+//     with the softmax VALU work of block n-1 in between, so exp/convert work hides in the MFMA shadows.
+//   * fixed softmax reference: a row's reference is set once from its first key block (+ a type-dependent bias)
+//     and the hot loop never tracks a running max or rescales O; if a row's scores later rise too far above it
+//     (block sum of P >= kPLimit) the whole workgroup redoes its query block with an exact online-softmax loop.
+//   * K/V tiles: global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, coalesced along head_dim, OOB rows land
+//     as zeros), XOR-swizzled through the per-lane SOURCE address so that both the row reads of K and the
+//     transposed reads of V are bank-conflict free; 4-deep ring, ONE barrier per 64-key tile, each tile's DMA
+//     has two iterations to land.
+//   * exp2 with scale*log2(e) folded in, deferred 1/l normalisation, causal block skipping + diagonal-only
+//     masking, LSE output.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -87,19 +86,14 @@ struct TypeF16 {
 
 constexpr int kBM = 256;          // query rows per workgroup
 constexpr int kBN = 64;           // keys per tile
-constexpr int kThreads = 512;
-constexpr float kRescaleThr = 8.0f;   // log2 units; 0 = rescale whenever any row max grows
-
-constexpr int kStages = 4;       // LDS ring depth (tiles) for K and for V (a power of two)
+constexpr int kStages = 4;        // LDS ring depth (tiles) for K and for V (a power of two)
+template <int QB> constexpr int threads_per_wg() { return 64 * (8 / QB); }
 template <int D> constexpr int lds_bytes() { return kStages * 2 /*K,V*/ * kBN * D * 2; }
 
 typedef __attribute__((address_space(3))) char lds_char;
 
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     return *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr);
-}
-__device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
-    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr) = v;
 }
 __device__ __forceinline__ u32x2 lds_read_tr16_b64(unsigned addr) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(addr));
@@ -147,22 +141,23 @@ template <int V> using IC = std::integral_constant<int, V>;
 
 struct SmState {
     f32x16 sv;        // (masked) scores of one 32-key block
-    float rs;         // this lane's partial row sum
+    float rs0, rs1;   // this lane's partial row sums (two independent chains)
 };
 
-template <class T, int D, bool CAUSAL>
-__global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
+template <class T, int D, bool CAUSAL, int QB>
+__global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const FwdParams p)
 {
+    constexpr int NWAVES = 8 / QB;
     constexpr int KS = D / 16;                 // k-steps of the QK^T product
     constexpr int DB = D / 32;                 // 32-wide head_dim blocks of O^T
     constexpr int ROWB = D * 2;                // bytes per K/V row in LDS
-    constexpr int CH = D / 8;                  // 16-byte chunks per row
     constexpr int TILE = kBN * ROWB;           // bytes per K (or V) tile
-    constexpr int CPT = (kBN * CH) / kThreads; // chunks per thread per tile (2 @ D=128, 1 @ D=64)
+    constexpr int PIECE = 1024;                // bytes one DMA wave-instruction moves
+    constexpr int CPT = TILE / PIECE / NWAVES; // DMA pieces per wave per tile
     static_assert(CPT >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // [buf][K|V][TILE]
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // K ring [kStages][TILE], then V ring
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -170,29 +165,22 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     const int r = lane & 31;
     const int hh = lane >> 5;
 
-    // ---- workgroup -> (head, query block).  blockIdx % 8 labels the XCD group: all query blocks
-    // of one head share an XCD (its L2 holds that head's K/V); heavy blocks first when causal.
+    // ---- workgroup -> (head, query block(s)).  blockIdx % 8 labels the XCD group: all query blocks of one
+    // head share an XCD (its L2 holds that head's K/V).  Causal: a workgroup processes the pair of query
+    // blocks (nqb-1-t, t) one after the other, so every workgroup carries the same number of key tiles
+    // (nqb+1 of them) and the grid is balanced however the dispatcher places it.
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int hl = slot / p.nqb;
-    const int qpos = slot - hl * p.nqb;
+    const int wg_per_head = CAUSAL ? (p.nqb + 1) / 2 : p.nqb;
+    const int hl = slot / wg_per_head;
+    const int tq = slot - hl * wg_per_head;
     const int head = hl * 8 + xcd;
     if (head >= p.bh) return;
-    const int qb = CAUSAL ? (p.nqb - 1 - qpos) : qpos;
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;
-
-    // waves w and w+4 share a SIMD: give them row blocks that sum to 7 so that the causal
-    // diagonal block is balanced across SIMDs.
-    const int rowblk = CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave;
-    const int q0w = qb * kBM + rowblk * 32;
-
-    const int kv_end_wg = CAUSAL ? min(S, qb * kBM + kBM) : S;
-    const int nt = (kv_end_wg + kBN - 1) / kBN;
-    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? min(S, q0w + 32) : S);
-    const int my_nt = (kv_end_w + kBN - 1) / kBN;
+    const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
     const elem_t* qh = reinterpret_cast<const elem_t*>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -204,28 +192,45 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + D) * 2);
     const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + D) * 2);
     __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(qh), 0, q_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(kh), 0, k_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(vh), 0, v_bytes, 0x00020000);
+    const u32x4 rk_w = make_rsrc(kh, k_bytes);
+    const u32x4 rv_w = make_rsrc(vh, v_bytes);
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[q0w + r][16 ks + 8 hh + 0..7]
-    u32x4 qf[KS];
-    {
-        const int qrow = q0w + r;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int qb = CAUSAL ? (pass == 0 ? p.nqb - 1 - tq : tq) : tq;
+
+    // 32-row query blocks of this wave.  QB = 1: waves w and w+4 share a SIMD and get row blocks that sum to 7
+    // so that the causal diagonal tile is balanced across SIMDs.  QB = 2: wave w owns row blocks 2w and 2w+1.
+    int q0[QB];
+    if constexpr (QB == 1) {
+        q0[0] = qb * kBM + (CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave) * 32;
+    } else {
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) q0[qi] = qb * kBM + (wave * QB + qi) * 32;
+    }
+    const int q_first = q0[0], q_last = q0[QB - 1];
+
+    const int kv_end_wg = CAUSAL ? min(S, qb * kBM + kBM) : S;
+    const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
+    const int kv_end_w = (q_first >= S) ? 0 : (CAUSAL ? min(S, q_last + 32) : S);
+    const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[q0 + r][16 ks + 8 hh + 0..7]
+    u32x4 qf[QB][KS];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        const int qrow = q0[qi] + r;
         // rows past the end of the sequence get an offset outside the descriptor: they read as zero
         const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + hh * 16) : 0x80000000u;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
+            qf[qi][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
     }
 
-    // ---- K/V staging by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR round trip.
-    // LDS: K ring [kStages][TILE], then V ring.  One wave-instruction writes a 1-KiB piece linearly
-    // (M0 base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE address: the lane that
-    // lands on LDS chunk position c' of row `row` fetches global chunk  c' ^ f(row)  of that row.
-    // Rows past the end of the sequence fall outside the descriptor and are written as zeros
-    // (the host guarantees (S + 256) * row_stride_bytes < 2^31: no 32-bit wrap).
+    // ---- K/V staging by LDS-DMA.  One wave-instruction writes a 1-KiB piece linearly (M0 base + lane*16), so
+    // the XOR swizzle is applied to the per-lane SOURCE address: the lane that lands on LDS chunk position c' of
+    // row `row` fetches global chunk  c' ^ f(row)  of that row.  Rows past the end of the sequence fall outside
+    // the descriptor and are written as zeros (the host guarantees (S + 256) * row_stride_bytes < 2^31).
     constexpr int VBASE = kStages * TILE;
-    constexpr int PIECE = 1024;
     unsigned g_koff[CPT], g_voff[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
@@ -237,8 +242,6 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * 2);
     const unsigned v_tile_stride = (unsigned)(kBN * p.v_ss * 2);
     const unsigned piece_base = lds_base + wave * CPT * PIECE;       // wave-uniform
-    const u32x4 rk_w = make_rsrc(kh, k_bytes);
-    const u32x4 rv_w = make_rsrc(vh, v_bytes);
     auto dma_k = [&](int j, unsigned stage_off) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     u32x4 vf[DB];
     auto read_kgroup = [&] __device__ (auto half_c, auto g_c) {
         constexpr int half = decltype(half_c)::value, g = decltype(g_c)::value;
-#if defined(FA_ABL_NOLDS)
+#if defined(FA_ABL_NOLDS)     // timing-only ablation builds (wrong results): see tools/ab_bench.py
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(kf[i]));
         return;
@@ -301,17 +304,21 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         }
     };
 
-    f32x16 o_acc[DB];
+    f32x16 o_acc[QB][DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int qi = 0; qi < QB; ++qi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o_acc[db][i] = 0.f;
-    float m_c = -INFINITY;     // running max reference, already multiplied by scale*log2(e)
-    float l_part = 0.f;        // this lane's share of the row sum (lanes r and r+32 are combined at the end)
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o_acc[qi][db][i] = 0.f;
+    float m_c[QB];             // softmax reference per row, already multiplied by scale*log2(e)
+    float l_part[QB];          // this lane's share of the row sum (lanes r and r+32 are combined at the end)
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) { m_c[qi] = -INFINITY; l_part[qi] = 0.f; }
     const float c = p.scale_log2;
 
-    f32x16 s_acc[2];           // S^T of block n (being produced) and n-1 (being consumed)
-    u32x4 pf[2][2];            // P^T fragments (2 k-steps of 16 keys) of block n-1 (produced) and n-2 (consumed)
+    f32x16 s_acc[QB][2];       // S^T of block n (being produced) and n-1 (being consumed)
+    u32x4 pf[QB][2][2];        // P^T fragments (2 k-steps of 16 keys) of block n-1 (produced) and n-2 (consumed)
 
     // ---- softmax of one 32-key block, in pieces that the pipeline block interleaves with its MFMA groups.
     // FAST PATH: the softmax reference m_c of a row is fixed once, from the row maximum of key block 0
@@ -320,12 +327,14 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     // If a block sum ever reaches kPLimit (scores far above the first block's), `p_peak` records it and the
     // whole workgroup redoes its query block with the exact online-softmax loop further below.
     float p_peak = 0.f;
-    auto sm_begin = [&] __device__ (auto mask_c, auto first_c, const f32x16& s_in, int key0, SmState& st) {
+    auto sm_begin = [&] __device__ (auto mask_c, auto first_c, auto qi_c, const f32x16& s_in, int key0, SmState& st) {
         constexpr bool MASK = decltype(mask_c)::value, FIRST = decltype(first_c)::value;
+        constexpr int qi = decltype(qi_c)::value;
         st.sv = s_in;
-        st.rs = 0.f;
+        st.rs0 = 0.f;
+        st.rs1 = 0.f;
         if constexpr (MASK) {
-            const int qrow = q0w + r;
+            const int qrow = q0[qi] + r;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             for (int i = 2; i < 16; ++i) mx = fmaxf(mx, st.sv[i]);
             auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(mx), bitcast<unsigned>(mx), false, false);
             mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
-            m_c = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, T::kPBias);
+            m_c[qi] = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, T::kPBias);
         }
     };
     // exponentials of scores [i0, i1) (i0, i1 even) against reference m_ref (already scaled); each pair is
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         constexpr int i0 = decltype(i0_c)::value, i1 = decltype(i1_c)::value;
 #pragma unroll
         for (int i = i0; i < i1; i += 2) {
-#if defined(FA_ABL_NOVALU)    // timing-only ablation builds (wrong results): see tools/ab_bench.py
+#if defined(FA_ABL_NOVALU)
             if (i == i0) { asm volatile("" : "+v"(st.sv)); pw[i >> 3][(i & 7) >> 1] = bitcast<unsigned>(st.sv[i]); }
             continue;
 #endif
@@ -360,15 +369,19 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st.sv[i + 1], c, -m_ref));
 #endif
 #if !defined(FA_ABL_NOSUM)
-            st.rs += p0;
-            st.rs += p1;
+            // pinned single-instruction adds: keep the two row-sum chains inside their region instead of
+            // letting the optimiser sink them (packed) behind the last MFMA of the block
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(st.rs0) : "v"(p0));
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(st.rs1) : "v"(p1));
 #endif
             pw[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
         }
     };
-    auto sm_end = [&] __device__ (SmState& st) {
-        l_part += st.rs;
-        p_peak = fmaxf(p_peak, st.rs);
+    auto sm_end = [&] __device__ (auto qi_c, SmState& st) {
+        constexpr int qi = decltype(qi_c)::value;
+        const float rs = st.rs0 + st.rs1;
+        l_part[qi] += rs;
+        p_peak = fmaxf(p_peak, rs);
     };
 
     // One pipeline block n (HALF = n & 1 selects the 32-key half of the 64-key tiles):
@@ -382,7 +395,21 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     auto mfma_pv = [&] __device__ (auto half_c, auto kstep_c) {
         constexpr int HALFv = decltype(half_c)::value, kstep = decltype(kstep_c)::value;
 #pragma unroll
-        for (int db = 0; db < DB; ++db) o_acc[db] = T::mfma(vf[db], pf[HALFv][kstep], o_acc[db]);
+        for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) o_acc[qi][db] = T::mfma(vf[db], pf[qi][HALFv][kstep], o_acc[qi][db]);
+    };
+    auto mfma_s = [&] __device__ (auto half_c, auto g_c) {
+        constexpr int HALFv = decltype(half_c)::value, g = decltype(g_c)::value;
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            if constexpr (g == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s_acc[qi][HALFv][i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_acc[qi][HALFv] = T::mfma(kf[i], qf[qi][4 * g + i], s_acc[qi][HALFv]);
+        }
     };
     auto advance = [&](int dk, int dv) {
 #pragma unroll
@@ -393,10 +420,8 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     auto block = [&] __device__ (auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, int n, int dk, int dv) {
         constexpr int HALF = decltype(half_c)::value;
         constexpr bool DO_S = decltype(do_s_c)::value, DO_SM = decltype(do_sm_c)::value, DO_PV = decltype(do_pv_c)::value;
-        f32x16& sw_ = s_acc[HALF];            // S(n)
-        const f32x16& sr_ = s_acc[HALF ^ 1];  // S(n-1)
-        u32x4 (&pw)[2] = pf[HALF ^ 1];        // P(n-1)
-        SmState st;
+        SmState st[QB];
+        const int key0 = (n - 1) * 32;
         // ---- region 0: PV k-step 0 | softmax head
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DO_PV) {
@@ -404,24 +429,29 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             read_vstep(IC<2 * HALF + 1>{});
         }
         if constexpr (DO_SM) {
-            sm_begin(mask_c, first_c, sr_, (n - 1) * 32, st);
-            sm_exp(st, pw, IC<0>{}, IC<4>{}, m_c);
+            sm_begin(mask_c, first_c, IC<0>{}, s_acc[0][HALF ^ 1], key0, st[0]);
+            sm_exp(st[0], pf[0][HALF ^ 1], IC<0>{}, IC<4>{}, m_c[0]);
+            if constexpr (QB == 2) {
+                sm_begin(mask_c, first_c, IC<QB - 1>{}, s_acc[QB - 1][HALF ^ 1], key0, st[QB - 1]);
+                sm_exp(st[QB - 1], pf[QB - 1][HALF ^ 1], IC<0>{}, IC<4>{}, m_c[QB - 1]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 1: S group 0 | exponentials
-        if constexpr (DO_S) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sw_[i] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sw_ = T::mfma(kf[i], qf[i], sw_);
-        }
+        if constexpr (DO_S) mfma_s(IC<HALF>{}, IC<0>{});
         if constexpr (GPB == 2) {
             if constexpr (DO_S) read_kgroup(IC<HALF>{}, IC<1>{});
-            if constexpr (DO_SM) sm_exp(st, pw, IC<4>{}, IC<8>{}, m_c);
+            if constexpr (DO_SM) {
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) sm_exp(st[qi], pf[qi][HALF ^ 1], IC<4>{}, IC<8>{}, m_c[qi]);
+            }
         } else {
             if constexpr (HALF == 1) advance(dk, dv);
             read_kgroup(IC<HALF ^ 1>{}, IC<0>{});             // next block's K fragments
-            if constexpr (DO_SM) sm_exp(st, pw, IC<4>{}, IC<12>{}, m_c);
+            if constexpr (DO_SM) {
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) sm_exp(st[qi], pf[qi][HALF ^ 1], IC<4>{}, IC<12>{}, m_c[qi]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 2: PV k-step 1 | exponentials
@@ -429,20 +459,24 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         if constexpr (GPB == 2) {
             if constexpr (HALF == 1) advance(dk, dv);
             read_vstep(IC<2 * (HALF ^ 1)>{});                 // next block's first V^T fragments
-            if constexpr (DO_SM) sm_exp(st, pw, IC<8>{}, IC<12>{}, m_c);
+            if constexpr (DO_SM) {
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) sm_exp(st[qi], pf[qi][HALF ^ 1], IC<8>{}, IC<12>{}, m_c[qi]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- region 3: S group 1 | exponentials
-            if constexpr (DO_S) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sw_ = T::mfma(kf[i], qf[4 + i], sw_);
-            }
+            if constexpr (DO_S) mfma_s(IC<HALF>{}, IC<1>{});
             read_kgroup(IC<HALF ^ 1>{}, IC<0>{});             // next block's first K fragments
         } else {
             read_vstep(IC<2 * (HALF ^ 1)>{});
         }
         if constexpr (DO_SM) {
-            sm_exp(st, pw, IC<12>{}, IC<16>{}, m_c);
-            sm_end(st);
+            sm_exp(st[0], pf[0][HALF ^ 1], IC<12>{}, IC<16>{}, m_c[0]);
+            sm_end(IC<0>{}, st[0]);
+            if constexpr (QB == 2) {
+                sm_exp(st[QB - 1], pf[QB - 1][HALF ^ 1], IC<12>{}, IC<16>{}, m_c[QB - 1]);
+                sm_end(IC<QB - 1>{}, st[QB - 1]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -489,8 +523,8 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
 
     const int NT = my_nt;                          // 64-key tiles this wave computes on
-    // first block whose softmax needs the mask (causal diagonal or ragged end)
-    const int mb = min(CAUSAL ? (q0w >> 5) : 0x7fffffff, S >> 5);
+    // first block whose softmax needs the mask (causal diagonal of the wave's first row block, or ragged end)
+    const int mb = min(CAUSAL ? (q_first >> 5) : 0x7fffffff, S >> 5);
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
     int j = 0;
     if (NT > 0) {
@@ -536,11 +570,14 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
     if (__syncthreads_or(!(p_peak < T::kPLimit))) {
         constexpr int KO = 0, VO = 2 * TILE;                  // two stages each: K at KO, V at VO
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+        for (int qi = 0; qi < QB; ++qi) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o_acc[db][i] = 0.f;
-        m_c = -INFINITY;
-        l_part = 0.f;
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o_acc[qi][db][i] = 0.f;
+            m_c[qi] = -INFINITY;
+            l_part[qi] = 0.f;
+        }
         unsigned ka2[KS], va2[DB];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) ka2[ks] = lds_base + KO + r * ROWB + k_swz<D>(r, 2 * ks + hh) * 16;
@@ -569,63 +606,68 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
                 const unsigned st = (jj & 1) * TILE;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    f32x16 sx;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sx[i] = 0.f;
+                    for (int qi = 0; qi < QB; ++qi) {
+                        f32x16 sx;
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-                        sx = T::mfma(lds_read_b128(ka2[ks] + st + half * 32 * ROWB), qf[ks], sx);
-                    const int qrow = q0w + r, key0 = jj * kBN + half * 32;
+                        for (int i = 0; i < 16; ++i) sx[i] = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        if ((key >= S) || (CAUSAL && key > qrow)) sx[i] = -INFINITY;
-                    }
-                    float mx = fmaxf(sx[0], sx[1]);
+                        for (int ks = 0; ks < KS; ++ks)
+                            sx = T::mfma(lds_read_b128(ka2[ks] + st + half * 32 * ROWB), qf[qi][ks], sx);
+                        const int qrow = q0[qi] + r, key0 = jj * kBN + half * 32;
 #pragma unroll
-                    for (int i = 2; i < 16; ++i) mx = fmaxf(mx, sx[i]);
-                    auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(mx), bitcast<unsigned>(mx), false, false);
-                    mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
-                    const float m_new = fmaxf(m_c, mx * c);
-                    const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_c - m_new);   // m_c = -inf -> 0
-                    l_part *= alpha;
-#pragma unroll
-                    for (int db = 0; db < DB; ++db)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) o_acc[db][i] *= alpha;
-                    m_c = m_new;
-                    const float m_sub = (m_c == -INFINITY) ? 0.f : m_c;       // row fully masked so far
-                    u32x4 px[2];
-#pragma unroll
-                    for (int i = 0; i < 16; i += 2) {
-                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[i], c, -m_sub));
-                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[i + 1], c, -m_sub));
-                        l_part += p0 + p1;
-                        px[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
-                    }
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                        for (int db = 0; db < DB; ++db) {
-                            const int sidx = 2 * half + s2;
-                            u32x2 lo = lds_read_tr16_b64(va2[db] + st + (16 * sidx) * ROWB);
-                            u32x2 hi = lds_read_tr16_b64(va2[db] + st + (16 * sidx + 8) * ROWB);
-                            o_acc[db] = T::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, px[s2], o_acc[db]);
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                            if ((key >= S) || (CAUSAL && key > qrow)) sx[i] = -INFINITY;
                         }
+                        float mx = fmaxf(sx[0], sx[1]);
+#pragma unroll
+                        for (int i = 2; i < 16; ++i) mx = fmaxf(mx, sx[i]);
+                        auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(mx), bitcast<unsigned>(mx), false, false);
+                        mx = fmaxf(bitcast<float>(sw[0]), bitcast<float>(sw[1]));
+                        const float m_new = fmaxf(m_c[qi], mx * c);
+                        const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_c[qi] - m_new);   // m_c = -inf -> 0
+                        l_part[qi] *= alpha;
+#pragma unroll
+                        for (int db = 0; db < DB; ++db)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) o_acc[qi][db][i] *= alpha;
+                        m_c[qi] = m_new;
+                        const float m_sub = (m_new == -INFINITY) ? 0.f : m_new;       // row fully masked so far
+                        u32x4 px[2];
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) {
+                            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[i], c, -m_sub));
+                            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[i + 1], c, -m_sub));
+                            l_part[qi] += p0 + p1;
+                            px[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int db = 0; db < DB; ++db) {
+                                const int sidx = 2 * half + s2;
+                                u32x2 lo = lds_read_tr16_b64(va2[db] + st + (16 * sidx) * ROWB);
+                                u32x2 hi = lds_read_tr16_b64(va2[db] + st + (16 * sidx + 8) * ROWB);
+                                o_acc[qi][db] = T::mfma(u32x4{lo[0], lo[1], hi[0], hi[1]}, px[s2], o_acc[qi][db]);
+                            }
+                    }
                 }
             }
         }
+        dma_wait<0>();
     }
 
     // ---- epilogue: combine the two lane halves' row sums, normalise, store O (and LSE)
-    {
-        auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(l_part), bitcast<unsigned>(l_part), false, false);
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(l_part[qi]), bitcast<unsigned>(l_part[qi]), false, false);
         const float l = bitcast<float>(sw[0]) + bitcast<float>(sw[1]);
         const float inv = (l > 0.f) ? 1.0f / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
-        const int qrow = q0w + r;
+        const int qrow = q0[qi] + r;
         if (p.lse != nullptr && hh == 0 && qrow < S) {
             // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)
-            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c[qi] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
         }
         // lane (r,hh) holds O[qrow][db*32 + 8g + 4hh + 0..3] in o_acc[db][4g..4g+3].
         // Pair column groups (g, g+1) with permlane32_swap so that each lane stores 16 contiguous bytes:
@@ -635,10 +677,11 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
         for (int db = 0; db < DB; ++db) {
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
-                unsigned a0 = T::pack2(o_acc[db][4 * g + 0] * inv, o_acc[db][4 * g + 1] * inv);
-                unsigned a1 = T::pack2(o_acc[db][4 * g + 2] * inv, o_acc[db][4 * g + 3] * inv);
-                unsigned b0 = T::pack2(o_acc[db][4 * g + 4] * inv, o_acc[db][4 * g + 5] * inv);
-                unsigned b1 = T::pack2(o_acc[db][4 * g + 6] * inv, o_acc[db][4 * g + 7] * inv);
+                const f32x16& oa = o_acc[qi][db];
+                unsigned a0 = T::pack2(oa[4 * g + 0] * inv, oa[4 * g + 1] * inv);
+                unsigned a1 = T::pack2(oa[4 * g + 2] * inv, oa[4 * g + 3] * inv);
+                unsigned b0 = T::pack2(oa[4 * g + 4] * inv, oa[4 * g + 5] * inv);
+                unsigned b1 = T::pack2(oa[4 * g + 6] * inv, oa[4 * g + 7] * inv);
                 auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                 // after the swap: lanes 0-31: {own a, upper's a} ; lanes 32-63: {lower's b, own b}
@@ -650,6 +693,8 @@ __global__ __launch_bounds__(kThreads, 2) void fa_fwd_kernel(const FwdParams p)
             }
         }
     }
+    if (pass + 1 < n_pass) __syncthreads();    // every wave is done with the LDS rings before they are restaged
+  }  // pass
 }
 
 }  // namespace fa

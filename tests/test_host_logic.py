@@ -76,7 +76,7 @@ def test_launch_info_geometry():
     lib = fa.load_library()
     g, b, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.fa_fwd_launch_info(8, 32, 4096, 128, 0, 1, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
-    assert (g.value, b.value, l.value) == (8 * 32 * 16, 512, 131072)     # cfg3: 4-stage K and V rings of 16 KiB tiles
+    assert (g.value, b.value, l.value) == (8 * 32 * 8, 512, 131072)      # cfg3: causal pairs of query blocks; 4-stage K and V rings of 16 KiB tiles
     assert lib.fa_fwd_launch_info(1, 3, 77, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
     assert (g.value, b.value, l.value) == (8, 512, 65536)                # heads padded to 8 XCD groups
     assert lib.fa_fwd_launch_info(1, 1, 8, 48, 0, 0, None, None, None) == -2
