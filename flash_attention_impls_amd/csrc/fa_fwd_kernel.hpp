@@ -63,7 +63,7 @@ template <class To, class From> __device__ __forceinline__ To bitcast(From f) { 
 // kPLimit: a per-lane block sum of P at or above this value flags the fixed-reference pass as unusable.
 struct TypeBF16 {
     static constexpr float kPBias = 0.0f;
-    static constexpr float kPLimit = 1.0e30f;
+    static constexpr float kPLimit = 1.152921504606846976e18f;   // 2^60: O stays far below the fp32 range
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8>(a), bitcast<bf16x8>(b), c, 0, 0, 0);
     }
@@ -369,10 +369,15 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
             const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st.sv[i + 1], c, -m_ref));
 #endif
 #if !defined(FA_ABL_NOSUM)
-            // pinned single-instruction adds: keep the two row-sum chains inside their region instead of
-            // letting the optimiser sink them (packed) behind the last MFMA of the block
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(st.rs0) : "v"(p0));
+#if defined(FA_ASM_ADD)
+            // pinned single-instruction adds (experiment).  NOT safe as written: hipcc pads no hazards for an
+            // asm consumer of a transcendental result (v_exp_f32 -> VALU read needs a wait state).
+            asm volatile("s_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(st.rs0) : "v"(p0));
             asm volatile("v_add_f32 %0, %0, %1" : "+v"(st.rs1) : "v"(p1));
+#else
+            st.rs0 += p0;           // two independent chains; the build uses -fno-slp-vectorize so that they
+            st.rs1 += p1;           // stay single-issue adds next to their exponentials
+#endif
 #endif
             pw[i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
         }

@@ -176,9 +176,9 @@ def test_large_logits_stability():
 
 
 @pytest.mark.parametrize("tile", [1, 5, 11])
-def test_forced_rescale_branch(tile):
-    """The lazy-rescale branch is data dependent: force it by making one key at a chosen KV tile
-    score far above everything before it (jump >> threshold), for a subset of the rows only."""
+def test_score_spike_within_fixed_reference_range(tile):
+    """One key at a chosen KV tile scores far above everything before it (2^43 above the first-block
+    reference for a subset of rows): bf16 P has the range, the fast fixed-reference path must stay exact."""
     B, H, S, D = 1, 1, 768, 128
     q, k, v = rand_qkv(B, H, S, D, torch.bfloat16, seed=21)
     q = q * 0.25
@@ -188,6 +188,47 @@ def test_forced_rescale_branch(tile):
         o, lse = fa.flash_attn(q, k, v, causal, return_lse=True)
         ref, lse_ref = ref_f64(q, k, v, causal)
         assert_close(o, ref, TOL["bf16"], f"spike at tile {tile} causal={causal}")
+        assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+@pytest.mark.parametrize("dt,amp", [("bf16", 160.0), ("fp16", 40.0)])
+@pytest.mark.parametrize("tile", [2, 9])
+@pytest.mark.parametrize("causal", [False, True])
+def test_forced_exact_fallback(dt, amp, tile, causal):
+    """Scores that rise beyond what the fixed softmax reference can hold (exp2 argument > 60 for bf16,
+    block sum >= 60000 for fp16) must send the workgroup through the exact online-softmax fallback:
+    spike one key so that a handful of rows overflow P, and compare the WHOLE tensor with float64."""
+    B, H, S, D = 1, 2, 1024, 128
+    q, k, v = rand_qkv(B, H, S, D, DT[dt], seed=33)
+    q = q * 0.25
+    key = tile * 64 + 5
+    k[0, 0, key] = (q[0, 0, 950] * amp).to(DT[dt])
+    k[0, 1, key + 64] = (q[0, 1, 700] * amp).to(DT[dt])
+    o, lse = fa.flash_attn(q, k, v, causal, return_lse=True)
+    ref, lse_ref = ref_f64(q, k, v, causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert_close(o, ref, TOL[dt], f"fallback {dt} tile {tile} causal={causal}")
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+    # the spiked rows really are beyond the fast path's range
+    s = (q[0, 0, 950].float() @ k[0, 0, key].float()) / math.sqrt(D) * 1.4427
+    assert s > (70 if dt == "bf16" else 25)
+
+
+def test_fallback_first_block_far_below_later_scores():
+    """First key block scores ~ -120 nats below the rest for every row: every workgroup falls back."""
+    B, H, S, D = 1, 2, 512, 64
+    q, k, v = rand_qkv(B, H, S, D, torch.bfloat16, seed=8)
+    k[:, :, :32] = 0                                   # first key block: score 0 for every query
+    # shift all later scores up by a large constant: add a common direction to q and to the later keys
+    u = torch.zeros(D, device="cuda")
+    u[0] = 1.0
+    q2 = (q.float() + 40 * u).to(torch.bfloat16)
+    k2 = k.clone()
+    k2[:, :, 32:] = (k[:, :, 32:].float() + 40 * u).to(torch.bfloat16)
+    for causal in (False, True):
+        o, lse = fa.flash_attn(q2, k2, v, causal, return_lse=True)
+        ref, lse_ref = ref_f64(q2, k2, v, causal)
+        assert_close(o, ref, TOL["bf16"], f"late scores dominate causal={causal}")
         assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
 
 

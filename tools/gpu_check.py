@@ -69,7 +69,12 @@ def timeit(B, H, S, D, dtype, causal, iters=20, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative build of the library to check")
     args = ap.parse_args()
+    if args.lib:
+        import importlib
+        fa_mod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+        fa_mod._lib_handle = fa_mod.load_library(args.lib)
     print(torch.cuda.get_device_name(0), flush=True)
     bf, hf = torch.bfloat16, torch.float16
     for (B, H, S, D, dt, c) in [
