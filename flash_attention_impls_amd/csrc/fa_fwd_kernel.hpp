@@ -160,10 +160,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // K ring [kStages][TILE], then V ring
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31;
-    const int hh = lane >> 5;
 
     // ---- workgroup -> (head, query block(s)).  blockIdx % 8 labels the XCD group: all query blocks of one
     // head share an XCD (its L2 holds that head's K/V).  Causal: a workgroup processes the pair of query
@@ -195,8 +192,16 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
 
+    u32x4 qf[QB][KS];          // Q fragments of the current pass (the next pass's are loaded behind its epilogue)
+
   for (int pass = 0; pass < n_pass; ++pass) {
     const int qb = CAUSAL ? (pass == 0 ? p.nqb - 1 - tq : tq) : tq;
+    // lane coordinates, made opaque per pass: everything derived from them (addresses, mask indices) is then
+    // recomputed inside the pass instead of being hoisted out of the pass loop and spilled around it
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 31;
+    const int hh = lane >> 5;
 
     // 32-row query blocks of this wave.  QB = 1: waves w and w+4 share a SIMD and get row blocks that sum to 7
     // so that the causal diagonal tile is balanced across SIMDs.  QB = 2: wave w owns row blocks 2w and 2w+1.
@@ -214,17 +219,22 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const int kv_end_w = (q_first >= S) ? 0 : (CAUSAL ? min(S, q_last + 32) : S);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[q0 + r][16 ks + 8 hh + 0..7]
-    u32x4 qf[QB][KS];
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[row0 + r][16 ks + 8 hh + 0..7]
+    auto load_q = [&](int qblk) {
 #pragma unroll
-    for (int qi = 0; qi < QB; ++qi) {
-        const int qrow = q0[qi] + r;
-        // rows past the end of the sequence get an offset outside the descriptor: they read as zero
-        const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + hh * 16) : 0x80000000u;
+        for (int qi = 0; qi < QB; ++qi) {
+            int row0;
+            if constexpr (QB == 1) row0 = qblk * kBM + (CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave) * 32;
+            else row0 = qblk * kBM + (wave * QB + qi) * 32;
+            const int qrow = row0 + r;
+            // rows past the end of the sequence get an offset outside the descriptor: they read as zero
+            const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + hh * 16) : 0x80000000u;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[qi][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
-    }
+            for (int ks = 0; ks < KS; ++ks)
+                qf[qi][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
+        }
+    };
+    if (pass == 0) load_q(qb);
 
     // ---- K/V staging by LDS-DMA.  One wave-instruction writes a 1-KiB piece linearly (M0 base + lane*16), so
     // the XOR swizzle is applied to the per-lane SOURCE address: the lane that lands on LDS chunk position c' of
@@ -492,11 +502,15 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     typedef std::integral_constant<int, 1> half1_t;
 
     // ---- prologue: K(0), V(0) must have landed before iteration 0; K(1), K(2), V(1) follow behind.
-    dma_k(0, 0);
-    dma_v(0, 0);
-    dma_k(1, TILE);
-    dma_k(2, 2 * TILE);
-    dma_v(1, TILE);
+    // (for the second query block of a causal pair this was issued behind the first one's main loop)
+    auto issue_prologue = [&]() {
+        dma_k(0, 0);
+        dma_v(0, 0);
+        dma_k(1, TILE);
+        dma_k(2, 2 * TILE);
+        dma_v(1, TILE);
+    };
+    if (pass == 0) issue_prologue();
     dma_wait<3 * CPT>();        // this wave's pieces of K(0), V(0) have landed ...
     __syncthreads();            // ... and every wave's are visible
 
@@ -661,6 +675,14 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
             }
         }
         dma_wait<0>();
+        __syncthreads();                       // every wave is done with the fallback's LDS stages
+    }
+
+    // ---- the next query block of a causal pair: its first tiles and its Q fragments travel while this
+    // block's output is normalised and stored (the rings are free: every wave passed the barrier above)
+    if (pass + 1 < n_pass) {
+        issue_prologue();
+        load_q(tq);
     }
 
     // ---- epilogue: combine the two lane halves' row sums, normalise, store O (and LSE)
@@ -698,7 +720,6 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
             }
         }
     }
-    if (pass + 1 < n_pass) __syncthreads();    // every wave is done with the LDS rings before they are restaged
   }  // pass
 }
 
