@@ -15,7 +15,7 @@ LIB_NAME = "libfa_mi355.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
 SOURCES = [os.path.join(CSRC, "fa_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "fa_fwd_kernel.hpp"),
+DEPS = SOURCES + [os.path.join(CSRC, "fa_fwd_kernel.hpp"), os.path.join(CSRC, "fa_fwd_kernel16.hpp"),
                   os.path.join(PKG_DIR, "..", "include", "fa_mi355.h")]
 
 # -fno-slp-vectorize: SLP packs the softmax's scalar f32 adds into v_pk_add_f32 chains placed behind the

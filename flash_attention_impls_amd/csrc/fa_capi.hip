@@ -15,6 +15,7 @@
 
 #include "../../include/fa_mi355.h"
 #include "fa_fwd_kernel.hpp"
+#include "fa_fwd_kernel16.hpp"
 
 // 32-row query blocks per wave: 1 = 8 waves per workgroup (two per SIMD), 2 = 4 waves (one per SIMD, 512 registers)
 #ifndef FA_QB
@@ -55,9 +56,32 @@ int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
+// head_dim 128: kernel on 16x16x32 MFMA tiles (fa_fwd_kernel16.hpp)
+template <class T, bool CAUSAL>
+int launch16(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::lds_bytes<128>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel16<T, CAUSAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel16<T, CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 template <class T, int D>
 int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
 {
+#if !defined(FA_MFMA32)
+    if constexpr (D == 128 && kQB == 1)
+        return causal ? launch16<T, true>(p, grid, s) : launch16<T, false>(p, grid, s);
+#endif
     return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
 }
 

@@ -33,6 +33,7 @@
 namespace fa {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -65,7 +66,20 @@ struct TypeBF16 {
     static constexpr float kPBias = 0.0f;
     static constexpr float kPLimit = 1.152921504606846976e18f;   // 2^60: O stays far below the fp32 range
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+#if defined(FA_ABL_MFMA16)   // timing-only: two 16x16x32 MFMAs (same FLOPs, same operands) in place of one 32x32x16
+        typedef __attribute__((ext_vector_type(4))) float f32x4;
+        f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bitcast<bf16x8>(a), bitcast<bf16x8>(b), c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bitcast<bf16x8>(a), bitcast<bf16x8>(b), c1, 0, 0, 0);
+        c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+        c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+        return c;
+#else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8>(a), bitcast<bf16x8>(b), c, 0, 0, 0);
+#endif
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bitcast<bf16x8>(a), bitcast<bf16x8>(b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
         f32x2 f = {a, b};
@@ -77,6 +91,9 @@ struct TypeF16 {
     static constexpr float kPLimit = 60000.0f;
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(bitcast<f16x8>(a), bitcast<f16x8>(b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(bitcast<f16x8>(a), bitcast<f16x8>(b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
         f32x2 f = {a, b};
