@@ -24,6 +24,10 @@
 #pragma once
 #include "fa_fwd_kernel.hpp"
 
+#ifndef FA_SGB_VARIANT
+#define FA_SGB_VARIANT 1
+#endif
+
 namespace fa {
 
 // V tile swizzle for the 16x16x32 transposed reads: a 32-lane half reads 8 consecutive keys x 32 bytes;
@@ -260,6 +264,36 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         typedef IC<HALF ^ 1> P_SM;          // parity of block n-1
         const int key0 = (n - 1) * 32;
         float rs0[2] = {0.f, 0.f}, rs1[2] = {0.f, 0.f};
+        // optional per-region interleave pattern for the scheduler (FA_SGB): R x {1 MFMA, n DS reads, m VALU/TRANS}
+        auto hint = [&] __device__ (auto nrd_c, auto nvalu_c) {
+#if !defined(FA_NO_SGB)
+            if constexpr (DO_S && DO_SM && DO_PV) {
+                constexpr int NRD = decltype(nrd_c)::value, NV = decltype(nvalu_c)::value;
+#if FA_SGB_VARIANT == 2
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRD / 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 2 * NV, 0);
+                }
+#elif FA_SGB_VARIANT == 3
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, NV, 0);
+                    if (NRD == 8 || (t & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#else
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (NRD == 8 || (t & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, NV, 0);
+                }
+#endif
+            }
+#endif
+        };
         // ---- region 0: PV, head_dim tiles 0..3 | softmax slice (kt 0, qt 0)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DO_PV) {
@@ -270,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
             if constexpr (FIRST) sm_set_reference(mask_c, P_SM{}, key0);
             sm_slice(mask_c, P_SM{}, IC<0>{}, IC<0>{}, key0, rs0[0], rs1[0]);
         }
+        hint(IC<8>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 1: S, key tile 0 | slice (kt 0, qt 1)
         if constexpr (DO_S) {
@@ -277,12 +312,14 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
             read_kgroup(IC<HALF>{}, IC<1>{});
         }
         if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<0>{}, IC<1>{}, key0, rs0[1], rs1[1]);
+        hint(IC<4>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 2: PV, head_dim tiles 4..7 | slice (kt 1, qt 0)
         if constexpr (DO_PV) mfma_pv(P_PV{}, IC<1>{});
         if constexpr (HALF == 1) advance(dk, dv);
         read_vgroup(IC<HALF ^ 1>{}, IC<0>{});                 // next block's first V^T fragments
         if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<1>{}, IC<0>{}, key0, rs0[0], rs1[0]);
+        hint(IC<8>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 3: S, key tile 1 | slice (kt 1, qt 1)
         if constexpr (DO_S) mfma_s(IC<HALF>{}, IC<1>{});
@@ -296,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
                 p_peak = fmaxf(p_peak, rs);
             }
         }
+        hint(IC<4>{}, IC<3>{});
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -330,6 +368,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     };
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
 
+#if defined(FA_PRIO)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     const int mb = min(CAUSAL ? (q0w >> 5) : 0x7fffffff, S >> 5);   // first block whose softmax needs the mask
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
