@@ -74,6 +74,16 @@ def cpu_baseline(w, target_s):
             "ms_per_iter": t * 1e3}
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
+    correction + WRITE_SIZE); collected in separate rocprofv3 --pmc runs of tools/prof_run.py, not in this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            return json.load(fh).get(workload)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -189,7 +199,9 @@ def main():
                        "flops_rule": "4*B*H*S^2*D, halved when causal (FA2 convention)"},
             "pct_mfma_peak": 100.0 * value / (world * peak),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak,
+                         "traffic": (measured_traffic(args.workload) or {}).get("bytes_per_launch"),
+                         "traffic_source": (measured_traffic(args.workload) or {}).get("source"),
                          "kernel_ms_avg": kernel_ms, "kernel_ms_min": kt[0],
                          "algorithmic_flops_per_launch": flops_rank,
                          "algorithmic_bytes_per_launch": bytes_rank,

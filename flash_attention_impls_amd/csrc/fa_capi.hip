@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -85,6 +86,35 @@ int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
     return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
 }
 
+// fp8 (OCP e4m3fn) -> bf16, exact (every e4m3 value is representable in bf16).  One thread converts 16 bytes
+// of one (b, h, s) row; rows are D contiguous bytes, addressed through the source strides, written contiguously.
+typedef __attribute__((ext_vector_type(2))) float cvt_f32x2;
+__global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* __restrict__ src, unsigned short* __restrict__ dst,
+                                                           long long rows, int D, int H, int S, long long sb, long long sh, long long ss)
+{
+    const int cpr = D / 16;                                   // 16-byte chunks per row
+    const long long total = rows * cpr;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / cpr;
+        const int ch = (int)(t - row * cpr);
+        const long long b = row / ((long long)H * S);
+        const long long rem = row - b * (long long)H * S;
+        const long long h = rem / S, sidx = rem - h * S;
+        const fa::u32x4 in = *reinterpret_cast<const fa::u32x4*>(src + b * sb + h * sh + sidx * ss + ch * 16);
+        fa::u32x4 out[2];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const cvt_f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[w], false);
+            const cvt_f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)in[w], true);
+            out[w >> 1][2 * (w & 1)] = fa::TypeBF16::pack2(lo[0], lo[1]);
+            out[w >> 1][2 * (w & 1) + 1] = fa::TypeBF16::pack2(hi[0], hi[1]);
+        }
+        fa::u32x4* o = reinterpret_cast<fa::u32x4*>(dst + row * D + ch * 16);
+        o[0] = out[0];
+        o[1] = out[1];
+    }
+}
+
 int grid_for(int B, int H, int S, bool causal)
 {
     const long long bh = (long long)B * H;
@@ -111,7 +141,7 @@ const char* fa_last_error(void) { return g_err; }
 
 int fa_supported(int dtype, int head_dim)
 {
-    if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16) return 0;
+    if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_FP8_E4M3) return 0;
     return (head_dim == 64 || head_dim == 128) ? 1 : 0;
 }
 
@@ -133,7 +163,8 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            const float* descale, void* stream)
 {
     g_err[0] = 0;
-    (void)descale;
+    if (dtype == FA_DTYPE_FP8_E4M3)
+        return fail(FA_ERR_BAD_DTYPE, "fp8 inputs need a workspace: call fa_fwd_fp8");
     if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_FP8_E4M3)
         return fail(FA_ERR_BAD_DTYPE, "unknown dtype code %d", dtype);
     if (D != 64 && D != 128)
@@ -169,8 +200,12 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
         return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", S, max_ss);
 
     const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
-    p.scale = scale;
-    p.scale_log2 = scale * 1.4426950408889634f;
+    // descale (used by fa_fwd_fp8 on its converted tensors): q and k scales fold into the softmax scale,
+    // the v scale multiplies the output
+    const float dq = descale ? descale[0] : 1.f, dkk = descale ? descale[1] : 1.f, dvv = descale ? descale[2] : 1.f;
+    p.scale = scale * dq * dkk;
+    p.scale_log2 = p.scale * 1.4426950408889634f;
+    p.out_scale = dvv;
 
     const int grid = grid_for(B, H, S, causal != 0);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
@@ -181,6 +216,50 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     if (dtype == FA_DTYPE_FP16)
         return D == 128 ? launch_c<fa::TypeF16, 128>(p, grid, c, s) : launch_c<fa::TypeF16, 64>(p, grid, c, s);
     return fail(FA_ERR_BAD_DTYPE, "dtype %d not compiled", dtype);
+}
+
+size_t fa_fp8_workspace_bytes(int B, int H, int S, int D)
+{
+    if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
+    return (size_t)3 * B * H * S * D * 2;               // bf16 copies of q, k, v
+}
+
+int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
+               int B, int H, int S, int D,
+               const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+               int causal, float softmax_scale, const float* descale,
+               void* workspace, size_t workspace_bytes, void* stream)
+{
+    g_err[0] = 0;
+    if (D != 64 && D != 128) return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (compiled: 64, 128)", D);
+    if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
+    if (B == 0 || H == 0 || S == 0) return FA_OK;
+    if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
+    if (workspace_bytes < fa_fp8_workspace_bytes(B, H, S, D))
+        return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, fa_fp8_workspace_bytes(B, H, S, D));
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
+    const void* src[3] = {q, k, v};
+    const int64_t* strd[3] = {q_strides, k_strides, v_strides};
+    const long long rows = (long long)B * H * S;
+    const size_t one = (size_t)rows * D * 2;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int t = 0; t < 3; ++t) {
+        long long sb, sh, ss;
+        if (!set_strides(strd[t], H, S, D, sb, sh, ss)) return fail(FA_ERR_BAD_STRIDE, "bad strides");
+        if (sb % 16 || sh % 16 || ss % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
+            return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
+        const long long chunks = rows * (D / 16);
+        const int blocks = (int)std::min<long long>((chunks + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(blocks), dim3(256), 0, s,
+                           reinterpret_cast<const unsigned char*>(src[t]),
+                           reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + t * one),
+                           rows, D, H, S, sb, sh, ss);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fp8 conversion launch failed: %s", hipGetErrorString(e));
+    }
+    char* w = static_cast<char*>(workspace);
+    return fa_fwd(w, w + one, w + 2 * one, o, lse, B, H, S, D, nullptr, nullptr, nullptr, o_strides,
+                  FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
 }
 
 int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,

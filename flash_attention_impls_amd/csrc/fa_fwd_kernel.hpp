@@ -55,6 +55,7 @@ struct FwdParams {
     long long o_sb, o_sh, o_ss;
     float scale;             // softmax scale (1/sqrt(D) by default: FA2-triton.py:183)
     float scale_log2;        // scale * log2(e)
+    float out_scale;         // multiplies O (V dequantisation scale of the fp8 entry; 1 otherwise)
 };
 
 template <class To, class From> __device__ __forceinline__ To bitcast(From f) { return __builtin_bit_cast(To, f); }
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     for (int qi = 0; qi < QB; ++qi) {
         auto sw = __builtin_amdgcn_permlane32_swap(bitcast<unsigned>(l_part[qi]), bitcast<unsigned>(l_part[qi]), false, false);
         const float l = bitcast<float>(sw[0]) + bitcast<float>(sw[1]);
-        const float inv = (l > 0.f) ? 1.0f / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
+        const float inv = (l > 0.f) ? p.out_scale / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
         const int qrow = q0[qi] + r;
         if (p.lse != nullptr && hh == 0 && qrow < S) {
             // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         float l = l_part[qt];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
-        const float inv = (l > 0.f) ? 1.0f / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
+        const float inv = (l > 0.f) ? p.out_scale / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
         const int qrow = q0w + 16 * qt + li;
         if (p.lse != nullptr && lg == 0 && qrow < S) {
             // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)

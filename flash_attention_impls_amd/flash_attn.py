@@ -56,6 +56,15 @@ def _declare(lib):
                            c.POINTER(c.c_int64), c.POINTER(c.c_int64),
                            c.c_int, c.c_int, c.c_float,
                            c.POINTER(c.c_float), c.c_void_p]
+    lib.fa_fp8_workspace_bytes.restype = c.c_size_t
+    lib.fa_fp8_workspace_bytes.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int]
+    lib.fa_fwd_fp8.restype = c.c_int
+    lib.fa_fwd_fp8.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                               c.c_int, c.c_int, c.c_int, c.c_int,
+                               c.POINTER(c.c_int64), c.POINTER(c.c_int64),
+                               c.POINTER(c.c_int64), c.POINTER(c.c_int64),
+                               c.c_int, c.c_float, c.POINTER(c.c_float),
+                               c.c_void_p, c.c_size_t, c.c_void_p]
     lib.fa_fwd_dispatch.restype = c.c_int
     lib.fa_fwd_dispatch.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                     c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p]
@@ -98,7 +107,8 @@ def _dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float8_e4m3fn:
         return FA_DTYPE_FP8_E4M3
     raise FlashAttnArgumentError(f"unsupported dtype {dt}; expected bfloat16, float16, float32 "
-                                 "(computed in float16 like the reference) or float8_e4m3fn")
+                                 "(computed in float16 like the reference) or float8_e4m3fn "
+                                 "(with descale=(q,k,v) per-tensor scales)")
 
 
 def _strides3(t: torch.Tensor):
@@ -170,10 +180,17 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
         dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
         with torch.cuda.device(q.device):
             stream = torch.cuda.current_stream().cuda_stream
-            rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(),
-                            lse.data_ptr() if lse is not None else None,
-                            B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
-                            code, 1 if causal else 0, scale, dsc, stream)
+            lse_ptr = lse.data_ptr() if lse is not None else None
+            if code == FA_DTYPE_FP8_E4M3:
+                nbytes = lib.fa_fp8_workspace_bytes(B, H, N, D)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+                rc = lib.fa_fwd_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
+                                    B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                                    1 if causal else 0, scale, dsc, ws.data_ptr(), nbytes, stream)
+            else:
+                rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
+                                B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                                code, 1 if causal else 0, scale, dsc, stream)
         if rc != 0:
             raise RuntimeError(f"fa_fwd failed ({rc}): {lib.fa_last_error().decode()}")
     if orig_dtype == torch.float32:

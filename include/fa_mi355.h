@@ -27,6 +27,7 @@
 #ifndef FA_MI355_H
 #define FA_MI355_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -38,7 +39,7 @@ extern "C" {
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
 #define FA_DTYPE_FP16     1
-#define FA_DTYPE_FP8_E4M3 2     /* OCP e4m3fn inputs, bf16 output */
+#define FA_DTYPE_FP8_E4M3 2     /* OCP e4m3fn inputs, bf16 output: through fa_fwd_fp8 (needs a workspace) */
 
 #define FA_OK               0
 #define FA_ERR_BAD_DTYPE   -1
@@ -68,8 +69,9 @@ const char* fa_last_error(void);
  *   lse     : nullable; contiguous [B, H, S] fp32, natural log-sum-exp of the scaled scores.
  *   causal  : non-zero = mask keys j > query i (top-left aligned, FA2-triton.py:70-73).
  *   softmax_scale : <= 0 selects 1/sqrt(D) (FA2-triton.py:183).
- *   descale : nullable, HOST pointer to 3 floats {q,k,v} per-tensor dequantisation scales,
- *             used with FA_DTYPE_FP8_E4M3 only (NULL = 1.0).
+ *   descale : nullable, HOST pointer to 3 floats {q,k,v} per-tensor scales: scores are multiplied by
+ *             descale[0]*descale[1], the output by descale[2] (NULL = 1.0).
+ *   dtype FA_DTYPE_FP8_E4M3 is rejected here (FA_ERR_BAD_DTYPE): use fa_fwd_fp8.
  */
 int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            int B, int H, int S, int D,
@@ -77,6 +79,22 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            const int64_t* v_strides, const int64_t* o_strides,
            int dtype, int causal, float softmax_scale,
            const float* descale, void* stream);
+
+/*
+ * fp8 (OCP e4m3fn) Q/K/V, bf16 O.  Round 1 implementation: the three tensors are converted (exactly) to bf16
+ * into the caller-provided device workspace by a HIP pre-pass, then the bf16 kernel runs with the q,k
+ * dequantisation scales folded into the softmax scale and the v scale into the output.  No reference
+ * counterpart (the reference is fp16 only); BASELINE.json config 5.
+ *   strides are in elements (= bytes) with unit head_dim stride; rows and bases 16-byte aligned.
+ *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes, 16-byte aligned.
+ */
+size_t fa_fp8_workspace_bytes(int B, int H, int S, int D);
+int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
+               int B, int H, int S, int D,
+               const int64_t* q_strides, const int64_t* k_strides,
+               const int64_t* v_strides, const int64_t* o_strides,
+               int causal, float softmax_scale, const float* descale,
+               void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Contiguous [B,H,N,D] convenience entry with the reference dispatcher's argument order

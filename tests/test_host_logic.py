@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     lib = fa.load_library()
     syms = declared_symbols()
     assert {"fa_fwd", "fa_fwd_dispatch", "fa_version", "fa_supported", "fa_last_error",
-            "fa_fwd_launch_info"} <= set(syms)
+            "fa_fwd_launch_info", "fa_fwd_fp8", "fa_fp8_workspace_bytes"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
     assert lib.fa_version() == 100
@@ -39,7 +39,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 
 def test_supported_matrix():
     lib = fa.load_library()
-    for dt in (0, 1):
+    assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 3 * 8 * 32 * 4096 * 128 * 2
+    for dt in (0, 1, 2):
         assert lib.fa_supported(dt, 64) == 1 and lib.fa_supported(dt, 128) == 1
         assert lib.fa_supported(dt, 32) == 0 and lib.fa_supported(dt, 256) == 0
     assert lib.fa_supported(7, 128) == 0

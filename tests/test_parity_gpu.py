@@ -68,6 +68,50 @@ def test_golden_vectors(name):
         assert orc.sym_rel_err(o.float().cpu().numpy()[big], ref[big]) < 0.02 * (8 if d["dtype"] == "bf16" else 1)
 
 
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("fp8")])
+def test_golden_vectors_fp8(name):
+    """fp8-e4m3fn Q/K/V with per-tensor scales (BASELINE config 5 dtype): HIP conversion pre-pass + bf16 kernel.
+    Stated tolerance: relative Frobenius error <= 5 %; the conversion is exact, so the bf16
+    element-wise bound holds as well."""
+    from conftest import FP8_REL_FRO
+    d = load_golden(name)
+    q, k, v = [golden_torch(d, n, "cuda") for n in "qkv"]
+    assert q.dtype == torch.float8_e4m3fn
+    ds = tuple(float(x) for x in d["descale"])
+    o, lse = fa.flash_attn(q, k, v, bool(d["causal"]), descale=ds, return_lse=True)
+    assert o.dtype == torch.bfloat16 and o.shape == q.shape
+    ref = d["o"].astype(np.float64)
+    of = o.float().cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    assert_close(o, ref, TOL["bf16"], name)
+    lse_ref = d["lse"].astype(np.float64)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+def test_fp8_strided_and_raw_capi():
+    """fa_fwd_fp8 through raw pointers with a caller-owned workspace; (B,S,H,D)-stored inputs."""
+    lib = _lib_loaded_from_tree()
+    B, H, S, D = 2, 3, 300, 128
+    g = torch.Generator().manual_seed(17)
+    base = [torch.randn(B, S, H, D, generator=g) for _ in range(3)]
+    sc = [float(t.abs().max()) / 448.0 for t in base]
+    q8, k8, v8 = [(t / s_).to(torch.float8_e4m3fn).cuda().permute(0, 2, 1, 3) for t, s_ in zip(base, sc)]
+    assert not q8.is_contiguous()
+    o = fa.flash_attn(q8, k8, v8, True, descale=tuple(sc))
+    qd, kd, vd = [t.float().cpu() * s_ for t, s_ in zip((q8, k8, v8), sc)]
+    ref, _ = orc.naive_attention_f64(qd.numpy(), kd.numpy(), vd.numpy(), causal=True)
+    assert_close(o, ref, TOL["bf16"], "fp8 strided")
+    # too-small workspace and plain fa_fwd with the fp8 code are rejected before any launch
+    ws = torch.empty(16, dtype=torch.uint8, device="cuda")
+    oc = torch.empty(B, H, S, D, dtype=torch.bfloat16, device="cuda")
+    rc = lib.fa_fwd_fp8(q8.data_ptr(), k8.data_ptr(), v8.data_ptr(), oc.data_ptr(), None, B, H, S, D,
+                        None, None, None, None, 1, ctypes.c_float(0.0), None, ws.data_ptr(), 16, None)
+    assert rc == -3 and b"workspace" in lib.fa_last_error()
+    rc = lib.fa_fwd(q8.data_ptr(), k8.data_ptr(), v8.data_ptr(), oc.data_ptr(), None, B, H, S, D,
+                    None, None, None, None, 2, 1, ctypes.c_float(0.0), None, None)
+    assert rc == -1 and b"fa_fwd_fp8" in lib.fa_last_error()
+
+
 # ------------------------------------------------------------------ shape grid vs oracle
 GRID = [(B, H, S, D, dt, c)
         for (B, H) in [(1, 2)]
