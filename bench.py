@@ -40,8 +40,11 @@ WORKLOADS = {
     "cfg2": dict(B=4, H=8, S=1024, D=64, dtype="bf16", causal=False),
     "cfg4": dict(B=1, H=16, S=16384, D=128, dtype="bf16", causal=True),
     "cfg3nc": dict(B=8, H=32, S=4096, D=128, dtype="bf16", causal=False),
+    # BASELINE config 5 per-GPU shard (64 batches over 8 GPUs = 8 per GPU): fp8-e4m3 Q/K/V with per-tensor scales;
+    # round 1 computes it with bf16 MFMAs after an exact fp8->bf16 HIP pre-pass (both inside the timed step)
+    "cfg5": dict(B=8, H=32, S=4096, D=128, dtype="fp8", causal=False),
 }
-DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.float8_e4m3fn}
 
 
 def parse():
@@ -53,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo only to rehearse the N>1 control flow on a one-GPU box (all ranks on cuda:0, no gather)")
     return ap.parse_args()
 
 
@@ -62,7 +67,7 @@ def cpu_baseline(w, target_s):
     from flash_attention_impls_amd.bench_utils import attn_flops
     cores = os.cpu_count() or 1
     B, H, S, D, causal = 1, min(4, w["H"]), w["S"], w["D"], w["causal"]
-    dt = DT[w["dtype"]]
+    dt = torch.bfloat16 if w["dtype"] == "fp8" else DT[w["dtype"]]      # fp8: CPU SDPA on the dequantised tensors
     t_probe, threads = orc.time_cpu_sdpa(B, H, S, D, dt, causal, iters=1, threads=cores)
     # scale the head count so the sample takes about target_s (bounded by the full head count)
     h_full = max(1, min(w["H"], int(H * (target_s / 3.0) / max(t_probe, 1e-4))))
@@ -95,12 +100,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = args.dist_backend == "gloo"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     else:
         dist = None
 
@@ -112,25 +122,39 @@ def main():
     B, H, S, D, causal = w["B"], w["H"], w["S"], w["D"], w["causal"]
     dt = DT[w["dtype"]]
     torch.manual_seed(0 + rank)
-    q = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
-    k = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
-    v = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+    descale = None
+    if w["dtype"] == "fp8":           # per-tensor amax/448 scales
+        f32 = [torch.randn(B, H, S, D, device=dev, dtype=torch.float32) for _ in range(3)]
+        descale = tuple(float(t.abs().max()) / 448.0 for t in f32)
+        q, k, v = [(t / s_).to(dt) for t, s_ in zip(f32, descale)]
+        del f32
+    else:
+        q = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+        k = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+        v = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
 
     # parity gate (small shape, oracle as the checker) before any timing is accepted
     parity = None
     if rank == 0:
         from oracle import attn_oracle as orc
         g = torch.Generator().manual_seed(1)
-        qs, ks, vs = (torch.randn(1, 2, 333, D, generator=g).to(dt) for _ in range(3))
-        o_s = fa.flash_attn(qs.to(dev), ks.to(dev), vs.to(dev), causal).float().cpu()
-        ref = orc.sdpa_oracle(qs.float(), ks.float(), vs.float(), causal)
+        if w["dtype"] == "fp8":
+            fs = [torch.randn(1, 2, 333, D, generator=g) for _ in range(3)]
+            dsc = tuple(float(t.abs().max()) / 448.0 for t in fs)
+            qs, ks, vs = [(t / s_).to(dt) for t, s_ in zip(fs, dsc)]
+            o_s = fa.flash_attn(qs.to(dev), ks.to(dev), vs.to(dev), causal, descale=dsc).float().cpu()
+            ref = orc.sdpa_oracle(*[t.float() * s_ for t, s_ in zip((qs, ks, vs), dsc)], causal)
+        else:
+            qs, ks, vs = (torch.randn(1, 2, 333, D, generator=g).to(dt) for _ in range(3))
+            o_s = fa.flash_attn(qs.to(dev), ks.to(dev), vs.to(dev), causal).float().cpu()
+            ref = orc.sdpa_oracle(qs.float(), ks.float(), vs.float(), causal)
         parity = float((o_s - ref).abs().max())
-        tol = 1.6e-2 if w["dtype"] == "bf16" else 2e-3
+        tol = 2e-3 if w["dtype"] == "fp16" else 1.6e-2
         if not parity <= tol * max(1.0, float(ref.abs().max())):
             sys.exit(f"parity gate failed: max|o-ref|={parity}")
 
     def step():
-        return fa.flash_attn(q, k, v, causal)
+        return fa.flash_attn(q, k, v, causal, descale=descale)
 
     def barrier():
         if dist is not None:
@@ -146,7 +170,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -162,14 +186,15 @@ def main():
     kernel_ms = sum(kt) / len(kt)
 
     flops_rank = attn_flops(B, H, S, D, causal)
-    bytes_rank = attn_bytes(B, H, S, D)
+    bytes_rank = attn_bytes(B, H, S, D, in_bytes=1 if w["dtype"] == "fp8" else 2)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops_rank / (elapsed / args.steps) / 1e12
-    peak = MFMA_PEAK_TFLOPS[w["dtype"]]
+    compute_dtype = "bf16" if w["dtype"] == "fp8" else w["dtype"]     # fp8 inputs are computed with bf16 MFMAs
+    peak = MFMA_PEAK_TFLOPS[compute_dtype]
     achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
 
     gather = None
-    if dist is not None and not args.no_gather:
+    if dist is not None and not args.no_gather and not rehearsal:
         o = step()
         full = torch.empty((world * B, H, S, D), dtype=o.dtype, device=dev)
         for _ in range(2):
@@ -191,7 +216,7 @@ def main():
             "metric": "attn_fwd_tflops", "value": value, "unit": "TFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
+            "vs_baseline": None, "dtype": compute_dtype, "input_dtype": w["dtype"], "data": "synthetic",
             "config": {"workload": f"{args.workload}: B={B} H={H} S={S} D={D} {w['dtype']} "
                                    f"{'causal' if causal else 'non-causal'} per GPU (BASELINE.json metric config)",
                        "B_per_gpu": B, "H": H, "S": S, "D": D, "causal": causal,

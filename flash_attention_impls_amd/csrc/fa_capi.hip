@@ -86,21 +86,22 @@ int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
     return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
 }
 
-// fp8 (OCP e4m3fn) -> bf16, exact (every e4m3 value is representable in bf16).  One thread converts 16 bytes
-// of one (b, h, s) row; rows are D contiguous bytes, addressed through the source strides, written contiguously.
+// fp8 (OCP e4m3fn) -> bf16, exact (every e4m3 value is representable in bf16).  HBM-bound streaming pass:
+// blockIdx.y = (batch, head) slice, a thread converts 16 bytes of one sequence row per step (16-byte loads,
+// 2 x 16-byte stores); rows are D contiguous bytes addressed through the source strides, written contiguously.
 typedef __attribute__((ext_vector_type(2))) float cvt_f32x2;
 __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* __restrict__ src, unsigned short* __restrict__ dst,
-                                                           long long rows, int D, int H, int S, long long sb, long long sh, long long ss)
+                                                           int D, int H, int S, long long sb, long long sh, long long ss)
 {
-    const int cpr = D / 16;                                   // 16-byte chunks per row
-    const long long total = rows * cpr;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const long long row = t / cpr;
-        const int ch = (int)(t - row * cpr);
-        const long long b = row / ((long long)H * S);
-        const long long rem = row - b * (long long)H * S;
-        const long long h = rem / S, sidx = rem - h * S;
-        const fa::u32x4 in = *reinterpret_cast<const fa::u32x4*>(src + b * sb + h * sh + sidx * ss + ch * 16);
+    const int bh = blockIdx.y;
+    const int b = bh / H, h = bh - b * H;
+    const unsigned char* sp = src + b * sb + h * sh;
+    unsigned short* dp = dst + (long long)bh * S * D;
+    const int cpr = D / 16;                                   // 16-byte chunks per row (8 or 4)
+    const int total = S * cpr;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int row = t / cpr, ch = t - row * cpr;
+        const fa::u32x4 in = *reinterpret_cast<const fa::u32x4*>(sp + (long long)row * ss + ch * 16);
         fa::u32x4 out[2];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
             out[w >> 1][2 * (w & 1)] = fa::TypeBF16::pack2(lo[0], lo[1]);
             out[w >> 1][2 * (w & 1) + 1] = fa::TypeBF16::pack2(hi[0], hi[1]);
         }
-        fa::u32x4* o = reinterpret_cast<fa::u32x4*>(dst + row * D + ch * 16);
+        fa::u32x4* o = reinterpret_cast<fa::u32x4*>(dp + (long long)t * 16);
         o[0] = out[0];
         o[1] = out[1];
     }
@@ -248,12 +249,13 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
         if (!set_strides(strd[t], H, S, D, sb, sh, ss)) return fail(FA_ERR_BAD_STRIDE, "bad strides");
         if (sb % 16 || sh % 16 || ss % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
             return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
-        const long long chunks = rows * (D / 16);
-        const int blocks = (int)std::min<long long>((chunks + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(blocks), dim3(256), 0, s,
+        const int per_slice = S * (D / 16);
+        const int bx = std::max(1, std::min((per_slice + 255) / 256, 64));
+        if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the fp8 pre-pass");
+        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(bx, B * H), dim3(256), 0, s,
                            reinterpret_cast<const unsigned char*>(src[t]),
                            reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + t * one),
-                           rows, D, H, S, sb, sh, ss);
+                           D, H, S, sb, sh, ss);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fp8 conversion launch failed: %s", hipGetErrorString(e));
     }
