@@ -155,44 +155,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     // fragment registers: one group of 4 K fragments, one group of 4 V^T fragments (re-read one group ahead)
     u32x4 kf[4];
     u32x4 vf[4];
-#if defined(FA_ABL_LDSNOWAIT)   // timing-only: the LDS reads are issued but nothing waits for them until much later
-    u32x4 dk_[4], dv_[4];
-    bool dummy_init = false;
-#endif
     auto read_kgroup = [&] __device__ (auto half_c, auto kt_c) {
         constexpr int half = decltype(half_c)::value, kt = decltype(kt_c)::value;
-#if defined(FA_ABL_LDSNOWAIT)
-        if (dummy_init) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { asm volatile("" :: "v"(dk_[ks])); dk_[ks] = lds_read_b128(ka[ks] + (32 * half + 16 * kt) * ROWB); }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]));
-            return;
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dk_[ks] = u32x4{0, 0, 0, 0};
-#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[ks] = lds_read_b128(ka[ks] + (32 * half + 16 * kt) * ROWB);
     };
     auto read_vgroup = [&] __device__ (auto half_c, auto grp_c) {
         constexpr int half = decltype(half_c)::value, grp = decltype(grp_c)::value;
-#if defined(FA_ABL_LDSNOWAIT)
-        if (dummy_init) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                asm volatile("" :: "v"(dv_[d]));
-                u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + (32 * half) * ROWB);
-                u32x2 hi = lds_read_tr16_b64(va[4 * grp + d] + (32 * half + 16) * ROWB);
-                dv_[d] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-#pragma unroll
-            for (int d = 0; d < 4; ++d) asm volatile("" : "+v"(vf[d]));
-            return;
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv_[d] = u32x4{0, 0, 0, 0};
-#endif
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + (32 * half) * ROWB);
@@ -414,9 +383,6 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         block(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, 1, dk, dv);
         end_iter();
         j = 1;
-#if defined(FA_ABL_LDSNOWAIT)
-        dummy_init = true;
-#endif
         const int ja = min(jm, NT);
         for (; j < ja; ++j) {                      // steady state, no masking
             begin_iter(j);
