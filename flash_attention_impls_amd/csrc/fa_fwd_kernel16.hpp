@@ -155,17 +155,21 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     // fragment registers: one group of 4 K fragments, one group of 4 V^T fragments (re-read one group ahead)
     u32x4 kf[4];
     u32x4 vf[4];
-    auto read_kgroup = [&] __device__ (auto half_c, auto kt_c) {
-        constexpr int half = decltype(half_c)::value, kt = decltype(kt_c)::value;
+    // stage_c >= 0: the address registers hold stage-0 bases and the ring stage is an immediate (unrolled loop);
+    // stage_c == -1: the address registers already carry the stage of the tile being read
+    auto read_kgroup = [&] __device__ (auto stage_c, auto half_c, auto kt_c) {
+        constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, kt = decltype(kt_c)::value;
+        constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half + 16 * kt) * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = lds_read_b128(ka[ks] + (32 * half + 16 * kt) * ROWB);
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = lds_read_b128(ka[ks] + off);
     };
-    auto read_vgroup = [&] __device__ (auto half_c, auto grp_c) {
-        constexpr int half = decltype(half_c)::value, grp = decltype(grp_c)::value;
+    auto read_vgroup = [&] __device__ (auto stage_c, auto half_c, auto grp_c) {
+        constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, grp = decltype(grp_c)::value;
+        constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half) * ROWB;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + (32 * half) * ROWB);
-            u32x2 hi = lds_read_tr16_b64(va[4 * grp + d] + (32 * half + 16) * ROWB);
+            u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + off);
+            u32x2 hi = lds_read_tr16_b64(va[4 * grp + d] + off + 16 * ROWB);
             vf[d] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
@@ -176,15 +180,14 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_c[2] = {-INFINITY, -INFINITY};   // softmax reference per query tile, times scale*log2(e)
-    float l_part[2] = {0.f, 0.f};            // this lane's share of the row sums
+    float l_a[2] = {0.f, 0.f}, l_b[2] = {0.f, 0.f};   // this lane's share of the row sums: two add chains per query tile
     const float c = p.scale_log2;
-    float p_peak = 0.f;
 
     f32x4 s_acc[2][2][2];      // S^T tiles [block parity][key tile][query tile]
     u32x4 pf[2][2];            // P^T fragments [block parity][query tile]
 
     // ---- softmax slice (kt, qt) of block n-1: 4 scores -> 4 exponentials -> 2 packed words of pf[par][qt]
-    auto sm_slice = [&] __device__ (auto mask_c, auto par_c, auto kt_c, auto qt_c, int key0, float& rs0, float& rs1) {
+    auto sm_slice = [&] __device__ (auto mask_c, auto par_c, auto kt_c, auto qt_c, int key0) {
         constexpr bool MASK = decltype(mask_c)::value;
         constexpr int par = decltype(par_c)::value, kt = decltype(kt_c)::value, qt = decltype(qt_c)::value;
         f32x4 sv = s_acc[par][kt][qt];
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[1], c, -m_c[qt]));
         const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[2], c, -m_c[qt]));
         const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[3], c, -m_c[qt]));
-        rs0 += p0; rs1 += p1; rs0 += p2; rs1 += p3;
+        l_a[qt] += p0; l_b[qt] += p1; l_a[qt] += p2; l_b[qt] += p3;
         pf[par][qt][2 * kt] = T::pack2(p0, p1);
         pf[par][qt][2 * kt + 1] = T::pack2(p2, p3);
     };
@@ -256,14 +259,16 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
 
     // One pipeline block n (HALF = n & 1): MFMA  PV(n-2) | S(n);  VALU softmax(n-1);  four fenced regions of
     // 8 MFMAs + one softmax slice + one fragment-group read each (see fa_fwd_kernel.hpp for the protocol).
-    auto block = [&] __device__ (auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, int n, int dk, int dv) {
+    auto block = [&] __device__ (auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, auto st_c, int n, int dk, int dv) {
+        constexpr int ST = decltype(st_c)::value;            // ring stage of K tile n >> 1, or -1 (runtime addresses)
+        typedef IC<ST> SK;                                   // K(j) stage
+        typedef IC<(ST < 0 ? -1 : ((ST + 3) & 3))> SV;      // V(j-1) stage
         constexpr int HALF = decltype(half_c)::value;
         constexpr bool DO_S = decltype(do_s_c)::value, DO_SM = decltype(do_sm_c)::value, DO_PV = decltype(do_pv_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
         typedef IC<HALF> P_PV;              // parity of block n-2 (= n)
         typedef IC<HALF ^ 1> P_SM;          // parity of block n-1
         const int key0 = (n - 1) * 32;
-        float rs0[2] = {0.f, 0.f}, rs1[2] = {0.f, 0.f};
         // optional per-region interleave pattern for the scheduler (FA_SGB): R x {1 MFMA, n DS reads, m VALU/TRANS}
         auto hint = [&] __device__ (auto nrd_c, auto nvalu_c) {
 #if !defined(FA_NO_SGB)
@@ -298,41 +303,35 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DO_PV) {
             mfma_pv(P_PV{}, IC<0>{});
-            read_vgroup(IC<HALF>{}, IC<1>{});
+            read_vgroup(SV{}, IC<HALF>{}, IC<1>{});
         }
         if constexpr (DO_SM) {
             if constexpr (FIRST) sm_set_reference(mask_c, P_SM{}, key0);
-            sm_slice(mask_c, P_SM{}, IC<0>{}, IC<0>{}, key0, rs0[0], rs1[0]);
+            sm_slice(mask_c, P_SM{}, IC<0>{}, IC<0>{}, key0);
         }
         hint(IC<8>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 1: S, key tile 0 | slice (kt 0, qt 1)
         if constexpr (DO_S) {
             mfma_s(IC<HALF>{}, IC<0>{});
-            read_kgroup(IC<HALF>{}, IC<1>{});
+            read_kgroup(SK{}, IC<HALF>{}, IC<1>{});
         }
-        if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<0>{}, IC<1>{}, key0, rs0[1], rs1[1]);
+        if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<0>{}, IC<1>{}, key0);
         hint(IC<4>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 2: PV, head_dim tiles 4..7 | slice (kt 1, qt 0)
         if constexpr (DO_PV) mfma_pv(P_PV{}, IC<1>{});
-        if constexpr (HALF == 1) advance(dk, dv);
-        read_vgroup(IC<HALF ^ 1>{}, IC<0>{});                 // next block's first V^T fragments
-        if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<1>{}, IC<0>{}, key0, rs0[0], rs1[0]);
+        typedef IC<(ST < 0 ? -1 : (HALF == 1 ? ((ST + 1) & 3) : ST))> SKn;      // stages the next block reads
+        typedef IC<(ST < 0 ? -1 : (HALF == 1 ? ST : ((ST + 3) & 3)))> SVn;
+        if constexpr (HALF == 1 && ST < 0) advance(dk, dv);
+        read_vgroup(SVn{}, IC<HALF ^ 1>{}, IC<0>{});          // next block's first V^T fragments
+        if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<1>{}, IC<0>{}, key0);
         hint(IC<8>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 3: S, key tile 1 | slice (kt 1, qt 1)
         if constexpr (DO_S) mfma_s(IC<HALF>{}, IC<1>{});
-        read_kgroup(IC<HALF ^ 1>{}, IC<0>{});                 // next block's first K fragments
-        if constexpr (DO_SM) {
-            sm_slice(mask_c, P_SM{}, IC<1>{}, IC<1>{}, key0, rs0[1], rs1[1]);
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                const float rs = rs0[qt] + rs1[qt];
-                l_part[qt] += rs;
-                p_peak = fmaxf(p_peak, rs);
-            }
-        }
+        read_kgroup(SKn{}, IC<HALF ^ 1>{}, IC<0>{});          // next block's first K fragments
+        if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<1>{}, IC<1>{}, key0);
         hint(IC<4>{}, IC<3>{});
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -367,6 +366,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
     };
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
+    auto sync_and_stage_c = [&] __device__ (auto st_c, int j) {      // same, ring stage of tile j known at compile time
+        constexpr int ST = decltype(st_c)::value;
+        dma_wait<2 * CPT>();
+        __syncthreads();
+        dma_k(j + 3, ((ST + 3) & (kStages - 1)) * TILE);
+        dma_v(j + 2, ((ST + 2) & (kStages - 1)) * TILE);
+    };
 
 #if defined(FA_PRIO)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -376,32 +382,59 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
     int j = 0;
     if (NT > 0) {
-        read_kgroup(IC<0>{}, IC<0>{});
+        read_kgroup(IC<-1>{}, IC<0>{}, IC<0>{});
         begin_iter(0);                             // iteration 0 (pipeline fill); softmax(0) fixes the reference
-        block(half0_t{}, Y{}, N{}, N{}, N{}, N{}, 0, 0, 0);
+        block(half0_t{}, Y{}, N{}, N{}, N{}, N{}, IC<-1>{}, 0, 0, 0);
         sync_and_stage(0);
-        block(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, 1, dk, dv);
+        block(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, IC<-1>{}, 1, dk, dv);
         end_iter();
         j = 1;
         const int ja = min(jm, NT);
+        // steady state, no masking, four tiles per trip: the ring stage of every LDS access is an immediate
+        // (no address arithmetic in the loop).  j = 1 on entry, so the stages run 1, 2, 3, 0.
+        if (j + 4 <= ja) {
+            const int sk0 = stage_k * TILE, sv0 = ((stage_k + 3) & 3) * TILE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ka[ks] -= sk0;           // stage-0 bases
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) va[dt] -= sv0;
+            for (; j + 4 <= ja; j += 4) {
+                block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j, 0, 0);
+                sync_and_stage_c(IC<1>{}, j);
+                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j + 1, 0, 0);
+                block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<2>{}, 2 * j + 2, 0, 0);
+                sync_and_stage_c(IC<2>{}, j + 1);
+                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<2>{}, 2 * j + 3, 0, 0);
+                block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<3>{}, 2 * j + 4, 0, 0);
+                sync_and_stage_c(IC<3>{}, j + 2);
+                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<3>{}, 2 * j + 5, 0, 0);
+                block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<0>{}, 2 * j + 6, 0, 0);
+                sync_and_stage_c(IC<0>{}, j + 3);
+                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<0>{}, 2 * j + 7, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ka[ks] += sk0;           // back to stage-carrying addresses (stage_k unchanged)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) va[dt] += sv0;
+        }
         for (; j < ja; ++j) {                      // steady state, no masking
             begin_iter(j);
-            block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, 2 * j, 0, 0);
+            block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j, 0, 0);
             sync_and_stage(j);
-            block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, 2 * j + 1, dk, dv);
+            block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
             end_iter();
         }
         for (; j < NT; ++j) {                      // steady state with masking (diagonal / ragged tiles)
             begin_iter(j);
-            block(half0_t{}, Y{}, Y{}, Y{}, Y{}, N{}, 2 * j, 0, 0);
+            block(half0_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j, 0, 0);
             sync_and_stage(j);
-            block(half1_t{}, Y{}, Y{}, Y{}, Y{}, N{}, 2 * j + 1, dk, dv);
+            block(half1_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
             end_iter();
         }
         begin_iter(j);                             // iteration NT (pipeline drain)
-        block(half0_t{}, N{}, Y{}, Y{}, Y{}, N{}, 2 * j, 0, 0);
+        block(half0_t{}, N{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j, 0, 0);
         if (j < nt) sync_and_stage(j);
-        block(half1_t{}, N{}, N{}, Y{}, N{}, N{}, 2 * j + 1, dk, dv);
+        block(half1_t{}, N{}, N{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
         end_iter();
         ++j;
     }
@@ -411,8 +444,10 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     }
 
     // ---- exact fallback (rare): plain per-tile online softmax with running max and rescale
+    // A lane's row-sum share below kPLimit bounds every P it produced (all terms are positive); NaN fails the test.
+    float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     dma_wait<0>();                                 // no DMA may still be writing LDS past this point
-    if (__syncthreads_or(!(p_peak < T::kPLimit))) {
+    if (__syncthreads_or(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit))) {
         constexpr int KO = 0, VO = VBASE;                     // two stages each: K at KO, V at VO
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
