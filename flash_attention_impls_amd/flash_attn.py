@@ -148,9 +148,6 @@ def check_args(q, k, v) -> None:
     D = q.shape[3]
     if D % 16 != 0 or D > 128:                          # FA2-triton.py:178
         raise FlashAttnArgumentError(f"head_dim must satisfy D % 16 == 0 and D <= 128; got {D}")
-    if D not in _SUPPORTED_HEAD_DIMS:
-        raise FlashAttnArgumentError(
-            f"head_dim {D} has no compiled gfx950 kernel yet (available: {_SUPPORTED_HEAD_DIMS})")
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
@@ -168,7 +165,19 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
         q, k, v = q.half(), k.half(), v.half()
     code = _dtype_code(q.dtype)
     lib = load_library()
-    B, H, N, D = q.shape
+    B, H, N, D_in = q.shape
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(D_in)             # FA2-triton.py:183 (of the caller's head_dim)
+    # Kernels exist for head_dim 64 and 128.  The reference accepts any D % 16 == 0, D <= 128 (:178): other
+    # sizes are zero-padded up to the next compiled size on the host (zeros add nothing to q.k, and the padded
+    # output columns are dropped) -- correct, at the padded size's cost.
+    D = 64 if D_in <= 64 else 128
+    if D != D_in:
+        pad = (0, D - D_in)
+        if code == FA_DTYPE_FP8_E4M3:
+            q, k, v = [torch.nn.functional.pad(t.view(torch.uint8), pad).view(torch.float8_e4m3fn) for t in (q, k, v)]
+        else:
+            q, k, v = [torch.nn.functional.pad(t, pad) for t in (q, k, v)]
     if not lib.fa_supported(code, D):
         raise FlashAttnArgumentError(f"no gfx950 kernel compiled for dtype={q.dtype}, head_dim={D}")
     q, k, v = _kernel_ready(q), _kernel_ready(k), _kernel_ready(v)
@@ -176,7 +185,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     o = torch.empty((B, H, N, D), dtype=out_dtype, device=q.device)        # FA2-triton.py:179
     lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
     if B * H * N > 0:
-        scale = float(softmax_scale) if softmax_scale is not None else 1.0 / math.sqrt(D)   # :183
+        scale = float(softmax_scale)
         dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
         with torch.cuda.device(q.device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -193,6 +202,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
                                 code, 1 if causal else 0, scale, dsc, stream)
         if rc != 0:
             raise RuntimeError(f"fa_fwd failed ({rc}): {lib.fa_last_error().decode()}")
+    if D != D_in:
+        o = o[..., :D_in].contiguous()
     if orig_dtype == torch.float32:
         o = o.to(orig_dtype)                              # FA2-triton.py:244
     return (o, lse) if return_lse else o

@@ -106,10 +106,13 @@ def test_head_dim_rule_matches_reference_assert():
         @property
         def is_cuda(self):
             return True
-    for D, msg in ((24, "D % 16"), (256, "D % 16"), (32, "no compiled gfx950 kernel")):
+    for D, msg in ((24, "D % 16"), (256, "D % 16"), (136, "D % 16")):
         t = torch.zeros(1, 1, 8, D).as_subclass(FakeCuda)
         with pytest.raises(fa.FlashAttnArgumentError, match=msg):
             fa.check_args(t, t, t)
+    for D in (16, 32, 48, 64, 80, 96, 112, 128):          # the reference's accepted head dims
+        t = torch.zeros(1, 1, 8, D).as_subclass(FakeCuda)
+        fa.check_args(t, t, t)
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -130,6 +130,28 @@ def test_shape_grid_vs_oracle(B, H, S, D, dt, causal):
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
 
 
+@pytest.mark.parametrize("D", [16, 32, 48, 80, 96, 112])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_other_head_dims_of_the_reference(D, dt):
+    """Every head_dim the reference accepts (D % 16 == 0, D <= 128, FA2-triton.py:178); the reference's own
+    harness pins D == 32 (:333).  Served by zero-padding to the next compiled size; scale stays 1/sqrt(D)."""
+    q, k, v = rand_qkv(1, 3, 300, D, DT[dt], seed=D)
+    for causal in (False, True):
+        o, lse = fa.flash_attn(q, k, v, causal, return_lse=True)
+        assert o.shape == q.shape and o.dtype == q.dtype
+        ref, lse_ref = ref_f64(q, k, v, causal)
+        assert_close(o, ref, TOL[dt], f"D={D} {dt} causal={causal}")
+        assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+def test_reference_main_configuration():
+    """The reference's __main__ shape: B=1, H=16, N=1024, D=32, fp16, causal (FA2-triton.py:9-16,333)."""
+    q, k, v = rand_qkv(1, 16, 1024, 32, torch.float16, seed=0)
+    o = fa.flash_attn(q, k, v, True)
+    ref, _ = ref_f64(q, k, v, True)
+    assert_close(o, ref, TOL["fp16"], "reference main config")
+
+
 def test_cfg2_full_size_vs_c_oracle(oracle_clib):
     """BASELINE configs[1]: (4,8,1024,64) bf16 non-causal, whole tensor against the C oracle."""
     q, k, v = rand_qkv(4, 8, 1024, 64, torch.bfloat16, seed=2)
