@@ -155,6 +155,14 @@ template <int D> __device__ __forceinline__ int v_swz(int row, int ch) {
     else return ch ^ (((row >> 1) & 1) << 2);
 }
 
+// experiment helpers (FA_ASM_SMFMA): bf16 32x32x16 MFMA with an arch-VGPR destination, issued through inline asm
+__device__ __forceinline__ void asm_mfma_bf16_first(f32x16& d, u32x4 a, u32x4 b) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void asm_mfma_bf16_acc(f32x16& d, u32x4 a, u32x4 b) {
+    asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+
 template <int V> using IC = std::integral_constant<int, V>;
 
 struct SmState {
@@ -436,12 +444,24 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
         constexpr int HALFv = decltype(half_c)::value, g = decltype(g_c)::value;
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
+#if !defined(FA_ASM_SMFMA)
             if constexpr (g == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s_acc[qi][HALFv][i] = 0.f;
             }
+#endif
+#if defined(FA_ASM_SMFMA)
+            // experiment (QB = 2): S accumulates in arch VGPRs through inline-asm MFMAs, while the compiler's own
+            // (AGPR-form) MFMAs keep O in the accumulator file -- no v_accvgpr_read per score.  bf16 only.
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (g == 0 && i == 0) asm_mfma_bf16_first(s_acc[qi][HALFv], kf[i], qf[qi][4 * g + i]);
+                else asm_mfma_bf16_acc(s_acc[qi][HALFv], kf[i], qf[qi][4 * g + i]);
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) s_acc[qi][HALFv] = T::mfma(kf[i], qf[qi][4 * g + i], s_acc[qi][HALFv]);
+#endif
         }
     };
     auto advance = [&](int dk, int dv) {
@@ -514,6 +534,93 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
         __builtin_amdgcn_sched_barrier(0);
     };
 
+#if defined(FA_ASM_SMFMA)
+    // ---- hand-ordered steady-state block for QB = 2, D = 128 (one wave per SIMD: the instruction order IS the
+    // schedule).  32 slots of {1 MFMA, half a softmax pair-unit (3-4 VALU), <= 1 LDS read}, each pinned by a fence.
+    //   slots  0.. 7: PV k-step 0           | softmax q-block 0, scores 0..7
+    //   slots  8..15: S group 0 (asm MFMA)  | softmax q-block 0, scores 8..15 | reads: V^T fragments of k-step 1
+    //   slots 16..23: PV k-step 1           | softmax q-block 1, scores 0..7  | reads: K fragments of group 1
+    //   slots 24..31: S group 1 (asm MFMA)  | softmax q-block 1, scores 8..15 | reads: next block's V^T k-step 0
+    //   tail        : next block's K fragments of group 0
+    auto block_hs = [&] __device__ (auto half_c, int n, int dk, int dv) {
+        static_assert(QB == 2 && D == 128, "hand-ordered block: QB = 2, head_dim 128");
+        constexpr int HALF = decltype(half_c)::value;
+        (void)n;
+        float t1 = 0.f, p0 = 0.f;
+        float rs0[2] = {0.f, 0.f}, rs1[2] = {0.f, 0.f};
+        // first half of pair-unit u (u = 0..15): two scaled differences, one exponential
+        auto unit_a = [&] __device__ (auto u_c) {
+            constexpr int u = decltype(u_c)::value, qi = u >> 3, i = 2 * (u & 7);
+            const f32x16& sv = s_acc[qi][HALF ^ 1];
+            const float t0 = __builtin_fmaf(sv[i], c, -m_c[qi]);
+            t1 = __builtin_fmaf(sv[i + 1], c, -m_c[qi]);
+            p0 = __builtin_amdgcn_exp2f(t0);
+        };
+        // second half: the other exponential, row-sum adds, 16-bit pack
+        auto unit_b = [&] __device__ (auto u_c) {
+            constexpr int u = decltype(u_c)::value, qi = u >> 3, i = 2 * (u & 7);
+            const float p1 = __builtin_amdgcn_exp2f(t1);
+            rs0[qi] += p0;
+            rs1[qi] += p1;
+            pf[qi][HALF ^ 1][i >> 3][(i & 7) >> 1] = T::pack2(p0, p1);
+        };
+        auto vread = [&] __device__ (auto s_c, auto db_c) {      // one V^T fragment (2 transposed reads)
+            constexpr int sidx = decltype(s_c)::value, db = decltype(db_c)::value;
+            u32x2 lo = lds_read_tr16_b64(va[db] + (16 * sidx) * ROWB);
+            u32x2 hi = lds_read_tr16_b64(va[db] + (16 * sidx + 8) * ROWB);
+            vf[db] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        };
+        auto kread = [&] __device__ (auto half2_c, auto g_c, auto i_c) {
+            constexpr int h2 = decltype(half2_c)::value, g = decltype(g_c)::value, i = decltype(i_c)::value;
+            kf[i] = lds_read_b128(ka[4 * g + i] + h2 * 32 * ROWB);
+        };
+#define FA_FENCE __builtin_amdgcn_sched_barrier(0)
+        FA_FENCE;
+        // ---- slots 0..7: PV k-step 0
+#define FA_PV_SLOT(S, KSTEP, U) \
+        { constexpr int qi_ = (S) >> 2, db_ = (S) & 3; \
+          o_acc[qi_][db_] = T::mfma(vf[db_], pf[qi_][HALF][KSTEP], o_acc[qi_][db_]); \
+          if (((S) & 1) == 0) unit_a(IC<(U)>{}); else unit_b(IC<(U)>{}); }
+        FA_PV_SLOT(0, 0, 0) FA_FENCE; FA_PV_SLOT(1, 0, 0) FA_FENCE; FA_PV_SLOT(2, 0, 1) FA_FENCE; FA_PV_SLOT(3, 0, 1) FA_FENCE;
+        FA_PV_SLOT(4, 0, 2) FA_FENCE; FA_PV_SLOT(5, 0, 2) FA_FENCE; FA_PV_SLOT(6, 0, 3) FA_FENCE; FA_PV_SLOT(7, 0, 3) FA_FENCE;
+        // ---- slots 8..15: S group 0; V^T fragments of k-step 1 (one fragment every other slot)
+#define FA_S_SLOT(S, G, U) \
+        { constexpr int qi_ = (S) >> 2, i_ = (S) & 3; \
+          if ((G) == 0 && i_ == 0) asm_mfma_bf16_first(s_acc[qi_][HALF], kf[i_], qf[qi_][4 * (G) + i_]); \
+          else asm_mfma_bf16_acc(s_acc[qi_][HALF], kf[i_], qf[qi_][4 * (G) + i_]); \
+          if (((S) & 1) == 0) unit_a(IC<(U)>{}); else unit_b(IC<(U)>{}); }
+        FA_S_SLOT(0, 0, 4) vread(IC<2 * HALF + 1>{}, IC<0>{}); FA_FENCE; FA_S_SLOT(1, 0, 4) FA_FENCE;
+        FA_S_SLOT(2, 0, 5) vread(IC<2 * HALF + 1>{}, IC<1>{}); FA_FENCE; FA_S_SLOT(3, 0, 5) FA_FENCE;
+        FA_S_SLOT(4, 0, 6) vread(IC<2 * HALF + 1>{}, IC<2>{}); FA_FENCE; FA_S_SLOT(5, 0, 6) FA_FENCE;
+        FA_S_SLOT(6, 0, 7) vread(IC<2 * HALF + 1>{}, IC<3>{}); FA_FENCE; FA_S_SLOT(7, 0, 7) FA_FENCE;
+        // ---- slots 16..23: PV k-step 1; K fragments of group 1
+        FA_PV_SLOT(0, 1, 8)  kread(IC<HALF>{}, IC<1>{}, IC<0>{}); FA_FENCE; FA_PV_SLOT(1, 1, 8)  FA_FENCE;
+        FA_PV_SLOT(2, 1, 9)  kread(IC<HALF>{}, IC<1>{}, IC<1>{}); FA_FENCE; FA_PV_SLOT(3, 1, 9)  FA_FENCE;
+        FA_PV_SLOT(4, 1, 10) kread(IC<HALF>{}, IC<1>{}, IC<2>{}); FA_FENCE; FA_PV_SLOT(5, 1, 10) FA_FENCE;
+        FA_PV_SLOT(6, 1, 11) kread(IC<HALF>{}, IC<1>{}, IC<3>{}); FA_FENCE; FA_PV_SLOT(7, 1, 11) FA_FENCE;
+        // ---- slots 24..31: S group 1; next block's V^T fragments of its k-step 0
+        if constexpr (HALF == 1) advance(dk, dv);
+        FA_S_SLOT(0, 1, 12) vread(IC<2 * (HALF ^ 1)>{}, IC<0>{}); FA_FENCE; FA_S_SLOT(1, 1, 12) FA_FENCE;
+        FA_S_SLOT(2, 1, 13) vread(IC<2 * (HALF ^ 1)>{}, IC<1>{}); FA_FENCE; FA_S_SLOT(3, 1, 13) FA_FENCE;
+        FA_S_SLOT(4, 1, 14) vread(IC<2 * (HALF ^ 1)>{}, IC<2>{}); FA_FENCE; FA_S_SLOT(5, 1, 14) FA_FENCE;
+        FA_S_SLOT(6, 1, 15) vread(IC<2 * (HALF ^ 1)>{}, IC<3>{}); FA_FENCE; FA_S_SLOT(7, 1, 15) FA_FENCE;
+        // ---- tail: next block's first K fragments; commit the row sums
+        kread(IC<HALF ^ 1>{}, IC<0>{}, IC<0>{}); kread(IC<HALF ^ 1>{}, IC<0>{}, IC<1>{});
+        kread(IC<HALF ^ 1>{}, IC<0>{}, IC<2>{}); kread(IC<HALF ^ 1>{}, IC<0>{}, IC<3>{});
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            const float rs = rs0[qi] + rs1[qi];
+            l_part[qi] += rs;
+            p_peak = fmaxf(p_peak, rs);
+        }
+        FA_FENCE;
+#undef FA_PV_SLOT
+#undef FA_S_SLOT
+#undef FA_FENCE
+    };
+#endif
+
+
     typedef std::true_type Y;
     typedef std::false_type N;
     typedef std::integral_constant<int, 0> half0_t;
@@ -574,6 +681,17 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
         end_iter();
         j = 1;
         const int ja = min(jm, NT);
+#if defined(FA_ASM_SMFMA)
+        if constexpr (QB == 2 && D == 128) {
+            for (; j < ja; ++j) {                  // steady state, no masking: hand-ordered blocks
+                begin_iter(j);
+                block_hs(half0_t{}, 2 * j, 0, 0);
+                sync_and_stage(j);
+                block_hs(half1_t{}, 2 * j + 1, dk, dv);
+                end_iter();
+            }
+        }
+#endif
         for (; j < ja; ++j) {                      // steady state, no masking
             begin_iter(j);
             block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, 2 * j, 0, 0);
