@@ -5,6 +5,7 @@ bf16, 2e-3 for fp16 (and fp32 inputs, which the reference computes in fp16); ref
 attention of the dtype-rounded inputs.  LSE: 1e-3 absolute (relative to max(1,|lse|)).
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -417,3 +418,40 @@ def test_capi_lse_nullable():
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(o, fa.flash_attn(q, k, v, True))
+
+
+# ------------------------------------------------------------------ alternative kernel builds
+@pytest.mark.parametrize("flags", [
+    ["-DFA_MFMA32"],                                        # head_dim 128 on the 32x32x16 kernel
+    ["-DFA_MFMA32", "-DFA_QB=2"],                            # 4 waves x 64 rows, compiler-scheduled
+    ["-DFA_MFMA32", "-DFA_QB=2", "-DFA_ASM_SMFMA"],          # ... with inline-asm S MFMAs and the hand-ordered block
+])
+def test_alternative_kernel_builds_match_default(flags, tmp_path):
+    """The compile-time variants kept for tuning stay correct: built here with hipcc and compared
+    with the default build on causal and non-causal head_dim-128 problems (same algorithm, so differences are at
+    rounding level; QB variants of one MFMA shape are bitwise identical)."""
+    import importlib
+    import shutil
+    import subprocess
+    from flash_attention_impls_amd import _build
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    so = str(tmp_path / "libfa_variant.so")
+    cmd = [_build.hipcc_path(), *_build.HIPCC_FLAGS, *flags, "-o", so, *_build.SOURCES]
+    subprocess.run(cmd, check=True, capture_output=True)
+    fa_mod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    default = fa.load_library()
+    variant = fa_mod.load_library(so)
+    q, k, v = rand_qkv(2, 3, 1100, 128, torch.bfloat16, seed=77)
+    try:
+        for causal in (False, True):
+            fa_mod._lib_handle = default
+            o0 = fa.flash_attn(q, k, v, causal)
+            fa_mod._lib_handle = variant
+            o1, lse1 = fa.flash_attn(q, k, v, causal, return_lse=True)
+            ref, lse_ref = ref_f64(q, k, v, causal)
+            assert_close(o1, ref, TOL["bf16"], f"{flags} causal={causal}")
+            assert np.abs(lse1.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+            assert (o1.float() - o0.float()).abs().max() <= 2 ** -6
+    finally:
+        fa_mod._lib_handle = default
