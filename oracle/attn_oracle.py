@@ -20,6 +20,12 @@ What is restated here (reference = santiweide/flash-attention-impls @ 2025-10-31
   a time: scores, max, exp/sum, weighted V sum), in float64.
 * ``sym_rel_err``            <- ``compute_max_relative_error``
   code/cutlass_cuda_fa1/run/test_flash_attn.cu:108-143 (|a-b|/(|a|+|b|+1e-5)).
+* ``naive_attention_bwd_f64`` / ``tiled_recompute_bwd`` <- ``_bwd_kernel``
+  code/triton_fa2/FA2-triton.py:98-170 (recompute p from the saved m, l :156;
+  dv = p^T dO :158, dP = dO v^T :159, dp_sum = rowsum(dP*p) :160,
+  dS = (dP - dp_sum*p)*scale :161, dQ += dS k :163, dK = dS^T q :164), and
+  ``sdpa_bwd_oracle`` <- autograd through ``sdpa_reference`` (what the reference's
+  ``fwd_bwd`` harness differentiates, :357-372).
 
 Parity pin: ``tests/golden/*.npz`` were produced by ``oracle/gen_golden.py``, which
 imports the reference's own ``sdpa_reference`` (and, for D<=64, runs its Triton
@@ -174,6 +180,107 @@ def tiled_online_softmax(q, k, v, causal: bool = False, scale: float | None = No
 
 
 # --------------------------------------------------------------------------
+# _bwd_kernel restatement (FA2-triton.py:98-170)
+# --------------------------------------------------------------------------
+def naive_attention_bwd_f64(q, k, v, do, causal: bool = False, scale: float | None = None):
+    """Closed-form float64 gradients of o = softmax(scale q k^T [+mask]) v.
+    q,k,v,do: numpy (B,H,N,D).  Returns (dq, dk, dv, delta) in float64, delta = rowsum(do*o)."""
+    q = np.asarray(q, dtype=np.float64)
+    k = np.asarray(k, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    do = np.asarray(do, dtype=np.float64)
+    B, H, N, D = q.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    s = np.einsum("bhid,bhjd->bhij", q, k) * scale                   # :147
+    if causal:
+        i = np.arange(N)[:, None]
+        j = np.arange(N)[None, :]
+        s = np.where(j > i, -np.inf, s)                              # :148-151
+    m = s.max(axis=-1, keepdims=True)
+    p = np.exp(s - m)
+    p /= p.sum(axis=-1, keepdims=True)                               # :156 (exp(qk-m)/l)
+    dv = np.einsum("bhij,bhid->bhjd", p, do)                         # :158
+    dp = np.einsum("bhid,bhjd->bhij", do, v)                         # :159
+    delta = (dp * p).sum(axis=-1, keepdims=True)                     # :160
+    ds = (dp - delta) * p * scale                                    # :161
+    dq = np.einsum("bhij,bhjd->bhid", ds, k)                         # :163
+    dk = np.einsum("bhij,bhid->bhjd", ds, q)                         # :164
+    return dq, dk, dv, delta[..., 0]
+
+
+def tiled_recompute_bwd(q, k, v, do, lse, causal: bool = False, scale: float | None = None,
+                        block_m: int = 128, block_n: int = 128, w_dtype: str | None = None,
+                        delta=None):
+    """fp32 tile loop of the reference backward: one program per BLOCK_M query rows sweeping all
+    BLOCK_N key tiles (:119-170), p recomputed from the saved statistics (here lse = m + ln l, so
+    p = exp(qk - lse), equal to exp(qk - m)/l :156).  REFERENCE DEFECT (not reproduced): :160-161 form
+    dS = (dP - rowsum_tile(dP*p) * p) * scale; the softmax Jacobian is dS = p * (dP - rowsum(dP*p)) * scale
+    with the sum over the whole row.  The interpreted reference kernel's dV equals autograd through
+    sdpa_reference, its dQ/dK do not (oracle/gen_golden.py prints both; tests/golden/bwd_fp16_d64_*.npz keep
+    them as *_kernel).  The restatement uses the correct form with delta = rowsum(do*o) (FlashAttention-2),
+    which is what autograd of the reference's own sdpa_reference yields.
+    w_dtype: round p and dS to 'bf16'/'fp16' before the three gradient products, as the MFMA path does.
+    Returns (dq, dk, dv) fp32."""
+    q = np.asarray(q, dtype=np.float32)
+    k = np.asarray(k, dtype=np.float32)
+    v = np.asarray(v, dtype=np.float32)
+    do = np.asarray(do, dtype=np.float32)
+    lse = np.asarray(lse, dtype=np.float32)
+    B, H, N, D = q.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    scale = np.float32(scale)
+    dq = np.zeros_like(q)
+    dk = np.zeros_like(k)
+    dv = np.zeros_like(v)
+    for b in range(B):
+        for h in range(H):
+            if delta is None:
+                # full-row softmax output in fp32 for delta
+                s_full = (q[b, h] @ k[b, h].T) * scale
+                if causal:
+                    s_full = np.where(np.arange(N)[None, :] > np.arange(N)[:, None], np.float32(-np.inf), s_full)
+                o_full = np.exp(s_full - lse[b, h][:, None]).astype(np.float32) @ v[b, h]
+                dl = (do[b, h] * o_full).sum(axis=1).astype(np.float32)
+            else:
+                dl = np.asarray(delta, dtype=np.float32)[b, h]
+            for row_start in range(0, N, block_m):                           # program_id(1) :121
+                rows = np.arange(row_start, min(row_start + block_m, N))
+                qt, dot = q[b, h, rows], do[b, h, rows]                      # :131-134
+                acc = np.zeros((len(rows), D), np.float32)                   # :141
+                for col_start in range(0, N, block_n):                       # :144
+                    cols = np.arange(col_start, min(col_start + block_n, N))
+                    kt, vt = k[b, h, cols], v[b, h, cols]
+                    qk = (qt @ kt.T).astype(np.float32) * scale              # :147
+                    if causal:
+                        qk = np.where(cols[None, :] > rows[:, None], np.float32(-np.inf), qk)   # :148-151
+                    p = np.exp(qk - lse[b, h, rows][:, None]).astype(np.float32)                 # :156
+                    dp = (dot @ vt.T).astype(np.float32)                     # :159
+                    ds = (dp - dl[rows][:, None]) * p * scale                # :160-161
+                    if w_dtype is not None:
+                        p = round_to_dtype(p, w_dtype)
+                        ds = round_to_dtype(ds, w_dtype)
+                    dv[b, h, cols] += (p.T @ dot).astype(np.float32)         # :158,166-167
+                    acc += (ds @ kt).astype(np.float32)                      # :163
+                    dk[b, h, cols] += (ds.T @ qt).astype(np.float32)         # :164,168-169
+                dq[b, h, rows] = acc                                         # :171-172
+    return dq, dk, dv
+
+
+def sdpa_bwd_oracle(q, k, v, do, causal: bool = False, scale: float | None = None):
+    """Autograd through the sdpa_reference restatement (fp32 math on CPU copies of the dtype-rounded
+    tensors).  Returns (o, dq, dk, dv) as fp32 torch tensors."""
+    B, H, N, D = q.shape
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    q2, k2, v2 = [t.detach().to("cpu", torch.float32).clone().requires_grad_(True) for t in (q, k, v)]
+    o = F.scaled_dot_product_attention(q2, k2, v2, is_causal=causal, scale=scale)
+    o.backward(do.detach().to("cpu", torch.float32))
+    return o.detach(), q2.grad, k2.grad, v2.grad
+
+
+# --------------------------------------------------------------------------
 # compute_max_relative_error restatement (test_flash_attn.cu:108-143)
 # --------------------------------------------------------------------------
 def sym_rel_err(a, b) -> float:
@@ -188,6 +295,11 @@ def sym_rel_err(a, b) -> float:
 def attn_flops(B, H, S, D, causal: bool) -> float:
     f = 4.0 * B * H * S * S * D                      # test_flash_attn.cu:308
     return f / 2 if causal else f                    # FA2 convention
+
+
+def attn_bwd_flops(B, H, S, D, causal: bool) -> float:
+    """Five N x N x D products (S, dP, dV, dK, dQ) = 2.5 x the forward (FlashAttention-2 convention)."""
+    return 2.5 * attn_flops(B, H, S, D, causal)
 
 
 def attn_bytes(B, H, S, D, in_bytes=2, out_bytes=2, lse=True) -> float:

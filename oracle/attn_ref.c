@@ -9,6 +9,8 @@
  *   - scale = 1/sqrt(D) supplied by caller:   code/triton_fa2/FA2-triton.py:183
  *   - final 1/l with l==0 guard:              code/cutlass_cuda_fa1/run/flash_attn_cutlass.cu:446-452
  *   - naive 3-pass baseline (fp64):           code/cutlass_cuda_fa1/run/test_flash_attn.cu:548-615
+ *   - backward with recomputed softmax:       code/triton_fa2/FA2-triton.py:98-170 (dS in the correct
+ *     p*(dP - rowsum(dP*p))*scale form; the reference's :160-161 is defective, see oracle/attn_oracle.py)
  *
  * Parity pin: checked in tests/test_oracle.py against tests/golden/*.npz, which
  * were produced from the reference's own sdpa_reference (oracle/gen_golden.py).
@@ -116,6 +118,57 @@ int oracle_attn_naive_f64(const float* q, const float* k, const float* v, double
         }
     }
     free(sc);
+    return 0;
+}
+
+/* Backward of o = softmax(scale q k^T [+mask]) v for upstream gradient d_o, float64 accumulation, one query
+ * row at a time (p recomputed from the row's own max / sum: FA2-triton.py:147-156; dv :158, dP :159,
+ * delta :160 over the whole row, dS :161 corrected, dQ :163, dK :164).  q,k,v,d_o: contiguous [B][H][N][D]
+ * fp32; dq,dk,dv: same shape, float64, overwritten. */
+int oracle_attn_bwd_f64(const float* q, const float* k, const float* v, const float* d_o,
+                        double* dq, double* dk, double* dv,
+                        int B, int H, int N, int D, int causal, double scale)
+{
+    double* p = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+    double* dp = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+    if (!p || !dp) { free(p); free(dp); return -2; }
+    memset(dq, 0, sizeof(double) * (size_t)B * H * N * D);
+    memset(dk, 0, sizeof(double) * (size_t)B * H * N * D);
+    memset(dv, 0, sizeof(double) * (size_t)B * H * N * D);
+    for (long bh = 0; bh < (long)B * H; ++bh) {
+        const float* qh = q + bh * (long)N * D;
+        const float* kh = k + bh * (long)N * D;
+        const float* vh = v + bh * (long)N * D;
+        const float* gh = d_o + bh * (long)N * D;
+        double* dqh = dq + bh * (long)N * D;
+        double* dkh = dk + bh * (long)N * D;
+        double* dvh = dv + bh * (long)N * D;
+        for (int i = 0; i < N; ++i) {
+            int lim = causal ? i + 1 : N;
+            double mx = -INFINITY, sum = 0.0, delta = 0.0;
+            for (int j = 0; j < lim; ++j) {
+                double dot = 0.0, g = 0.0;
+                for (int d = 0; d < D; ++d) {
+                    dot += (double)qh[(long)i * D + d] * (double)kh[(long)j * D + d];
+                    g += (double)gh[(long)i * D + d] * (double)vh[(long)j * D + d];       /* dP :159 */
+                }
+                p[j] = dot * scale;
+                dp[j] = g;
+                if (p[j] > mx) mx = p[j];
+            }
+            for (int j = 0; j < lim; ++j) { p[j] = exp(p[j] - mx); sum += p[j]; }
+            for (int j = 0; j < lim; ++j) { p[j] /= sum; delta += p[j] * dp[j]; }          /* :156,160 */
+            for (int j = 0; j < lim; ++j) {
+                double ds = p[j] * (dp[j] - delta) * scale;                                /* :161 */
+                for (int d = 0; d < D; ++d) {
+                    dvh[(long)j * D + d] += p[j] * (double)gh[(long)i * D + d];            /* :158 */
+                    dqh[(long)i * D + d] += ds * (double)kh[(long)j * D + d];              /* :163 */
+                    dkh[(long)j * D + d] += ds * (double)qh[(long)i * D + d];              /* :164 */
+                }
+            }
+        }
+    }
+    free(p); free(dp);
     return 0;
 }
 

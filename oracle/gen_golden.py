@@ -11,6 +11,13 @@ What is executed from the reference (imported as a module, nothing copied):
 Inputs: g = torch.Generator().manual_seed(seed); q,k,v = randn(B,H,S,D, generator=g)
 in that order (fp32), optionally multiplied by `mul`, then cast to the case dtype.
 bf16 tensors are stored as uint16 bit patterns, fp8-e4m3fn as uint8 bit patterns.
+Backward fixtures (bwd_*.npz): "dq","dk","dv" (fp32) = autograd through the reference's
+sdpa_reference on fp32 copies of the dtype-rounded q,k,v with upstream gradient "do" (4th randn of the
+same generator, dtype-rounded); "o" = that forward output rounded to the dtype (what a forward pass
+saves), "delta" = rowsum(do*o).  Where the reference's Triton _bwd_kernel can be interpreted (fp16,
+D<=64, N a multiple of 128) its results are stored as "dq_kernel","dk_kernel","dv_kernel": its dV agrees
+with autograd, its dQ/dK do NOT (FA2-triton.py:160-161 forms dS = (dP - rowsum_tile(dP*p)*p)*scale
+instead of p*(dP - rowsum(dP*p))*scale) -- recorded as a reference defect, not reproduced.
 "lse" is computed in float64 from the dtype-rounded inputs (log-sum-exp of
 scale*q.k over unmasked keys); where the interpreted reference kernel ran,
 lse == m + log(l) is asserted to 2e-3 (fp16 kernel arithmetic).
@@ -43,6 +50,19 @@ CASES = [
     ("bf16_d128_s513",      1, 1, 513, 128, "bf16", True,  7, 1.0, False),
     ("fp8_d128_nc",         1, 2, 256, 128, "fp8",  False, 8, 1.0, False),
     ("fp8_d128_causal",     1, 2, 256, 128, "fp8",  True,  9, 1.0, False),
+]
+
+BWD_CASES = [
+    # name, B,H,S,D, dtype, causal, seed, run_triton_kernel
+    ("bwd_fp16_d64_causal",   1, 2, 256, 64,  "fp16", True,  20, True),
+    ("bwd_fp16_d64_nc",       1, 1, 128, 64,  "fp16", False, 21, True),
+    ("bwd_bf16_d128_causal",  1, 2, 256, 128, "bf16", True,  22, False),
+    ("bwd_bf16_d128_nc",      1, 1, 192, 128, "bf16", False, 23, False),
+    ("bwd_bf16_d128_ragged",  1, 2, 200, 128, "bf16", True,  24, False),
+    ("bwd_bf16_d64_ragged_nc", 1, 3, 77,  64,  "bf16", False, 25, False),
+    ("bwd_fp16_d128_nc",      1, 1, 320, 128, "fp16", False, 26, False),
+    ("bwd_bf16_d128_s1",      1, 1, 1,   128, "bf16", True,  27, False),
+    ("bwd_bf16_d128_s513",    1, 1, 513, 128, "bf16", True,  28, False),
 ]
 
 TORCH_DT = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
@@ -126,7 +146,53 @@ def main():
         print(f"{name}: o.sum={float(o.float().sum()):.6f} |o|.sum={float(o.float().abs().sum()):.6f}")
 
 
+def main_bwd():
+    ref = load_reference()
+    for (name, B, H, S, D, dtype, causal, seed, run_kernel) in BWD_CASES:
+        g = torch.Generator().manual_seed(seed)
+        dt = TORCH_DT[dtype]
+        q, k, v, do = [torch.randn(B, H, S, D, generator=g).to(dt) for _ in range(4)]
+        qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+        o32 = ref.sdpa_reference(qf, kf, vf, causal=causal)              # FA2-triton.py:311-323
+        o32.backward(do.float())
+        o = o32.detach().to(dt)
+        scale = 1.0 / math.sqrt(D)
+        s = torch.einsum("bhid,bhjd->bhij", q.double(), k.double()) * scale
+        if causal:
+            s = s.masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], float("-inf"))
+        lse = torch.logsumexp(s, dim=-1)
+        store = {"q": to_storage(q, dtype), "k": to_storage(k, dtype), "v": to_storage(v, dtype),
+                 "do": to_storage(do, dtype), "o": to_storage(o, dtype),
+                 "dq": qf.grad.numpy().copy(), "dk": kf.grad.numpy().copy(), "dv": vf.grad.numpy().copy(),
+                 "lse": lse.numpy().astype(np.float32),
+                 "delta": (do.float() * o.float()).sum(-1).numpy().copy()}
+        if run_kernel:
+            assert dtype == "fp16" and D <= 64 and S % ref.BLOCK_M == 0
+            o_k = torch.empty_like(q)
+            m = torch.empty(B, H, S, dtype=torch.float32)
+            l = torch.empty(B, H, S, dtype=torch.float32)
+            grid = (B * H, (S + ref.BLOCK_M - 1) // ref.BLOCK_M)
+            kw = dict(is_causal=causal, BLOCK_M_=ref.BLOCK_M, BLOCK_N_=ref.BLOCK_N, BLOCK_D_=min(ref.BLOCK_D, D))
+            ref._fwd_kernel[grid](q, k, v, o_k, m, l, B, H, S, D, *q.stride(), *k.stride(), *v.stride(),
+                                  *o_k.stride(), *m.stride(), *l.stride(), scale, **kw)
+            dq_k, dk_k, dv_k = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+            ref._bwd_kernel[grid](q, k, v, do, dq_k, dk_k, dv_k, m, l, B, H, S, D,
+                                  *q.stride(), *k.stride(), *v.stride(), *do.stride(),
+                                  *dq_k.stride(), *dk_k.stride(), *dv_k.stride(), *m.stride(), *l.stride(),
+                                  scale, **kw)
+            store.update(dq_kernel=dq_k.numpy().copy(), dk_kernel=dk_k.numpy().copy(), dv_kernel=dv_k.numpy().copy())
+            e = [float((a.float() - b).abs().max()) for a, b in ((dq_k, qf.grad), (dk_k, kf.grad), (dv_k, vf.grad))]
+            print(f"  {name}: reference _bwd_kernel vs autograd(sdpa_reference): dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+            assert e[2] < 4e-3, (name, e)
+        meta = dict(B=B, H=H, S=S, D=D, causal=int(causal), seed=seed)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), dtype=np.array(dtype),
+                            **{k_: np.array(v_) for k_, v_ in meta.items()}, **store)
+        print(f"{name}: dq.sum={float(qf.grad.sum()):.6f} dk.sum={float(kf.grad.sum()):.6f} dv.sum={float(vf.grad.sum()):.6f}")
+
+
 if __name__ == "__main__":
     if not os.path.exists(REF):
         sys.exit("reference not present: golden vectors can only be generated in the build container")
-    main()
+    if "--bwd-only" not in sys.argv:
+        main()
+    main_bwd()

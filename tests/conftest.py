@@ -22,8 +22,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names():
+def _all_golden():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_names():
+    """Forward fixtures."""
+    return [n for n in _all_golden() if not n.startswith("bwd_")]
+
+
+def golden_bwd_names():
+    """Backward fixtures (q,k,v,do,o,lse,delta,dq,dk,dv)."""
+    return [n for n in _all_golden() if n.startswith("bwd_")]
 
 
 def load_golden(name):
@@ -76,6 +86,8 @@ def oracle_clib():
                                         c.c_float, c.c_int, c.c_int]
     lib.oracle_attn_naive_f64.restype = c.c_int
     lib.oracle_attn_naive_f64.argtypes = [fp, fp, fp, dp, dp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_double]
+    lib.oracle_attn_bwd_f64.restype = c.c_int
+    lib.oracle_attn_bwd_f64.argtypes = [fp, fp, fp, fp, dp, dp, dp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_double]
     lib.oracle_sym_rel_err.restype = c.c_double
     lib.oracle_sym_rel_err.argtypes = [fp, fp, c.c_long]
     return lib
@@ -97,3 +109,18 @@ def c_oracle_fwd(lib, q, k, v, causal, scale=None, block_m=64, block_n=64):
                                  float(scale), block_m, block_n)
     assert rc == 0
     return o, lse
+
+
+def c_oracle_bwd(lib, q, k, v, do, causal, scale=None):
+    """Run the C backward oracle on fp32 numpy (B,H,N,D) arrays -> (dq, dk, dv) float64."""
+    q, k, v, do = [np.ascontiguousarray(t, np.float32) for t in (q, k, v, do)]
+    B, H, N, D = q.shape
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+    outs = [np.empty(q.shape, np.float64) for _ in range(3)]
+    fp = ctypes.POINTER(ctypes.c_float)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = lib.oracle_attn_bwd_f64(*[t.ctypes.data_as(fp) for t in (q, k, v, do)], *[t.ctypes.data_as(dp) for t in outs],
+                                 B, H, N, D, int(causal), float(scale))
+    assert rc == 0
+    return outs

@@ -1,0 +1,61 @@
+"""All BASELINE.json single-GPU configurations with the reference harness' semantics
+(measure_latency: 10 warm-ups, 100 per-iteration event timings, mean/std/min; code/triton_fa2/FA2-triton.py:249-268,
+340-354): ms, TFLOP/s, % of the dense bf16 MFMA peak, algorithmic GB/s, tokens/s, peak memory, max|o - SDPA|."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import torch.nn.functional as F
+
+from flash_attention_impls_amd import flash_attn
+from flash_attention_impls_amd.bench_utils import attn_bytes, attn_flops, measure_latency
+
+CONFIGS = [
+    ("cfg2", 4, 8, 1024, 64, torch.bfloat16, False),
+    ("cfg3", 8, 32, 4096, 128, torch.bfloat16, True),
+    ("cfg3-noncausal", 8, 32, 4096, 128, torch.bfloat16, False),
+    ("cfg3-fp16", 8, 32, 4096, 128, torch.float16, True),
+    ("cfg4", 1, 16, 16384, 128, torch.bfloat16, True),
+    ("cfg5-shard(fp8 in)", 8, 32, 4096, 128, torch.float8_e4m3fn, False),
+    ("ref-main D=32", 1, 16, 1024, 32, torch.float16, True),
+    ("ref-latency D=128 N=8192", 1, 32, 8192, 128, torch.float16, False),
+]
+
+
+def main():
+    print(torch.cuda.get_device_name(0))
+    print(f"{'config':26s} {'shape':22s} {'dtype':13s} {'causal':6s} {'mean ms':>9s} {'std':>7s} {'min ms':>8s} "
+          f"{'TFLOP/s':>8s} {'%peak':>6s} {'GB/s':>7s} {'Mtok/s':>8s} {'peakMB':>8s} {'max|o-sdpa|':>11s}", flush=True)
+    for name, B, H, S, D, dt, causal in CONFIGS:
+        torch.manual_seed(0)
+        f32 = [torch.randn(B, H, S, D, device="cuda") for _ in range(3)]
+        descale = None
+        if dt == torch.float8_e4m3fn:
+            descale = tuple(float(t.abs().max()) / 448.0 for t in f32)
+            q, k, v = [(t / s).to(dt) for t, s in zip(f32, descale)]
+            deq = [t[:1, :2].float() * s for t, s in zip((q, k, v), descale)]
+        else:
+            q, k, v = [t.to(dt) for t in f32]
+            deq = [t[:1, :2].float() for t in (q, k, v)]
+        del f32
+        o = flash_attn(q, k, v, causal, descale=descale)
+        # on-box SDPA (fp32 math) on a two-head slice as the accuracy spot check
+        ref = F.scaled_dot_product_attention(deq[0], deq[1], deq[2], is_causal=causal, scale=1 / math.sqrt(D))
+        err = float((o[:1, :2].float() - ref).abs().max())
+        del deq, ref
+        torch.cuda.reset_peak_memory_stats()
+        m = measure_latency(lambda: flash_attn(q, k, v, causal, descale=descale), warmup=10, iters=100)
+        peak_mb = torch.cuda.max_memory_allocated() / 1e6
+        fl = attn_flops(B, H, S, D, causal)
+        by = attn_bytes(B, H, S, D, in_bytes=q.element_size())
+        sec = m["mean_ms"] * 1e-3
+        tf = fl / sec / 1e12
+        print(f"{name:26s} {str((B, H, S, D)):22s} {str(dt)[6:]:13s} {str(causal):6s} {m['mean_ms']:9.4f} "
+              f"{m['std_ms']:7.4f} {m['min_ms']:8.4f} {tf:8.1f} {100 * tf / 2516.6:6.1f} {by / sec / 1e9:7.0f} "
+              f"{B * H * S / sec / 1e6:8.1f} {peak_mb:8.0f} {err:11.3e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
