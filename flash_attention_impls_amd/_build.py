@@ -14,9 +14,10 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libfa_mi355.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
-SOURCES = [os.path.join(CSRC, "fa_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "fa_fwd_kernel.hpp"), os.path.join(CSRC, "fa_fwd_kernel16.hpp"),
-                  os.path.join(PKG_DIR, "..", "include", "fa_mi355.h")]
+SOURCES = [os.path.join(CSRC, "fa_capi.hip"), os.path.join(CSRC, "fa_bwd_capi.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, n) for n in ("fa_fwd_kernel.hpp", "fa_fwd_kernel16.hpp", "fa_bwd_kernel.hpp",
+                                                  "fa_capi_common.hpp")] + \
+    [os.path.join(PKG_DIR, "..", "include", "fa_mi355.h")]
 
 # -fno-slp-vectorize: SLP packs the softmax's scalar f32 adds into v_pk_add_f32 chains placed behind the
 # MFMAs of a block (measured -2.6 % on the forward kernel); the kernel wants single-issue VALU fillers.

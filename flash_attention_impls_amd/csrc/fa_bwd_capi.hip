@@ -1,0 +1,165 @@
+// C-ABI launcher of the gfx950 FlashAttention backward (see include/fa_mi355.h).
+//
+// Host-side counterpart of the reference's _FlashAttnFn.backward (code/triton_fa2/FA2-triton.py:207-237):
+// there, dQ/dK/dV are zero-filled (:211-213) and one kernel adds dK/dV with fp16 atomics; here three launches
+// write every output exactly once (pre-pass, dQ kernel, dK/dV kernel), nothing needs zeroing.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/fa_mi355.h"
+#include "fa_capi_common.hpp"
+#include "fa_bwd_kernel.hpp"
+
+namespace {
+
+using fa_capi::fail;
+using fa_capi::g_err;
+using fa_capi::set_strides;
+
+template <class T, int D, int MODE, bool CAUSAL>
+int launch_bwd(const fa::BwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::bwd_lds_bytes<D, MODE>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_bwd_kernel<T, D, MODE, CAUSAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_bwd_kernel<T, D, MODE, CAUSAL>), dim3(grid), dim3(64 * fa::bwd_waves<MODE>()), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "backward kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+template <class T, int D>
+int run_bwd(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s)
+{
+    int rc = causal ? launch_bwd<T, D, 0, true>(pq, grid_q, s) : launch_bwd<T, D, 0, false>(pq, grid_q, s);
+    if (rc != FA_OK) return rc;
+    return causal ? launch_bwd<T, D, 1, true>(pk, grid_k, s) : launch_bwd<T, D, 1, false>(pk, grid_k, s);
+}
+
+template <class T, int D>
+int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int B, int H, int S, int Spad,
+             long long o_sb, long long o_sh, long long o_ss, long long g_sb, long long g_sh, long long g_ss, hipStream_t s)
+{
+    constexpr int RPB = 256 / (D / 8);
+    hipLaunchKernelGGL((fa::fa_bwd_prep_kernel<T, D>), dim3((Spad + RPB - 1) / RPB, B * H), dim3(256), 0, s,
+                       o, d_o, lse, stats, H, S, Spad, B * H, o_sb, o_sh, o_ss, g_sb, g_sh, g_ss);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "backward pre-pass launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+int bwd_grid(long long bh, long long blocks_per_head)
+{
+    const long long g = ((bh + 7) / 8) * 8 * blocks_per_head;   // heads padded to a multiple of 8 XCD groups
+    return g > 0x7FFFFFFFll ? -1 : (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fa_bwd_workspace_bytes(int B, int H, int S)
+{
+    if (B <= 0 || H <= 0 || S <= 0) return 0;
+    const size_t spad = ((size_t)S + fa::kBN - 1) / fa::kBN * fa::kBN;
+    return (size_t)2 * B * H * spad * sizeof(float);
+}
+
+int fa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+           void* dq, void* dk, void* dv,
+           int B, int H, int S, int D,
+           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+           const int64_t* o_strides, const int64_t* do_strides,
+           const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
+           int dtype, int causal, float softmax_scale,
+           void* workspace, size_t workspace_bytes, void* stream)
+{
+    g_err[0] = 0;
+    if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16)
+        return fail(FA_ERR_BAD_DTYPE, "backward supports bf16 and fp16 (dtype code %d)", dtype);
+    if (D != 64 && D != 128)
+        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (compiled: 64, 128)", D);
+    if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
+    if (B == 0 || H == 0 || S == 0) return FA_OK;
+    if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !workspace)
+        return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
+    if (workspace_bytes < fa_bwd_workspace_bytes(B, H, S))
+        return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, fa_bwd_workspace_bytes(B, H, S));
+    if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the backward pre-pass");
+
+    long long st[8][3];
+    const int64_t* given[8] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
+    const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
+    long long max_ss = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (!set_strides(given[i], H, S, D, st[i][0], st[i][1], st[i][2]))
+            return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
+        for (int c = 0; c < 3; ++c)
+            if ((st[i][c] * 2) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "stride %lld elements is not 16-byte aligned", st[i][c]);
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "tensor base pointer not 16-byte aligned");
+        max_ss = std::max(max_ss, st[i][2]);
+    }
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
+    // 32-bit buffer offsets inside one (batch, head) slice, with room for two prefetched tiles
+    if (((long long)S + 4 * fa::kBN) * max_ss * 2 >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", S, max_ss);
+    const int Spad = (S + fa::kBN - 1) / fa::kBN * fa::kBN;
+    if ((long long)2 * B * H * Spad * 4 + 4 * fa::kBN * 4 >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "row statistics exceed 2 GiB (B*H*S = %lld)", (long long)B * H * S);
+
+    const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* stats = static_cast<float*>(workspace);
+
+    int rc;
+    if (dtype == FA_DTYPE_BF16)
+        rc = D == 128 ? run_prep<fa::TypeBF16, 128>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
+                      : run_prep<fa::TypeBF16, 64>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
+    else
+        rc = D == 128 ? run_prep<fa::TypeF16, 128>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
+                      : run_prep<fa::TypeF16, 64>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
+    if (rc != FA_OK) return rc;
+
+    fa::BwdParams pq;
+    memset(&pq, 0, sizeof(pq));
+    pq.stats = stats;
+    pq.B = B; pq.H = H; pq.S = S; pq.Spad = Spad; pq.bh = B * H;
+    pq.scale = scale;
+    pq.scale_log2 = scale * 1.4426950408889634f;
+    fa::BwdParams pk = pq;
+    // MODE 0 (dQ): stationary Q, dO; streamed K, V
+    pq.x1 = q; pq.x2 = d_o; pq.y1 = k; pq.y2 = v; pq.out1 = dq; pq.out2 = nullptr;
+    pq.x1_sb = st[0][0]; pq.x1_sh = st[0][1]; pq.x1_ss = st[0][2];
+    pq.x2_sb = st[4][0]; pq.x2_sh = st[4][1]; pq.x2_ss = st[4][2];
+    pq.y1_sb = st[1][0]; pq.y1_sh = st[1][1]; pq.y1_ss = st[1][2];
+    pq.y2_sb = st[2][0]; pq.y2_sh = st[2][1]; pq.y2_ss = st[2][2];
+    pq.o1_sb = st[5][0]; pq.o1_sh = st[5][1]; pq.o1_ss = st[5][2];
+    pq.nxb = (S + 32 * fa::bwd_waves<0>() - 1) / (32 * fa::bwd_waves<0>());
+    // MODE 1 (dK, dV): stationary K, V; streamed Q, dO
+    pk.x1 = k; pk.x2 = v; pk.y1 = q; pk.y2 = d_o; pk.out1 = dk; pk.out2 = dv;
+    pk.x1_sb = st[1][0]; pk.x1_sh = st[1][1]; pk.x1_ss = st[1][2];
+    pk.x2_sb = st[2][0]; pk.x2_sh = st[2][1]; pk.x2_ss = st[2][2];
+    pk.y1_sb = st[0][0]; pk.y1_sh = st[0][1]; pk.y1_ss = st[0][2];
+    pk.y2_sb = st[4][0]; pk.y2_sh = st[4][1]; pk.y2_ss = st[4][2];
+    pk.o1_sb = st[6][0]; pk.o1_sh = st[6][1]; pk.o1_ss = st[6][2];
+    pk.o2_sb = st[7][0]; pk.o2_sh = st[7][1]; pk.o2_ss = st[7][2];
+    pk.nxb = (S + 32 * fa::bwd_waves<1>() - 1) / (32 * fa::bwd_waves<1>());
+
+    const int grid_q = bwd_grid((long long)B * H, pq.nxb), grid_k = bwd_grid((long long)B * H, pk.nxb);
+    if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
+    const bool c = causal != 0;
+    if (dtype == FA_DTYPE_BF16)
+        return D == 128 ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
+    return D == 128 ? run_bwd<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,399 @@
+// FlashAttention backward for gfx950 (MI355X / CDNA4) -- device code.
+//
+// Replaces (behaviourally) the reference's recompute backward:
+//   _bwd_kernel                  code/triton_fa2/FA2-triton.py:98-170
+// with the softmax Jacobian in its correct form dS = P o (dP - delta) * scale, delta = rowsum(dO o O)
+// (the reference's :160-161 is defective; its dV is reproduced, its dQ/dK are not).
+//
+// No atomics and no cross-workgroup sums: the gradient is computed by two launches of ONE kernel template,
+//   MODE 0 (dQ)     : a workgroup owns 256 query rows (8 waves x 32) and streams the K / V tiles of its head;
+//   MODE 1 (dK, dV) : a workgroup owns 128 keys (4 waves x 32, the 512-register file: two 32x128 f32
+//                     accumulators per wave) and streams the Q / dO tiles of its head.
+// Both recompute S and dP (7 matrix products for the 5 of the textbook count); in exchange dQ needs no f32
+// atomics (their chip-wide rate, ~1.3 TB/s, would bound the kernel: MI355X_MICROARCH.md 'Global float
+// atomics'), no f32 staging buffer and no conversion pass, and every output is bitwise reproducible.
+//
+// Common structure ("stationary" X rows live in registers as B operands, "streamed" Y tiles pass through LDS):
+//   scores   T1[y][x] = Y1 . X1^T,  T2[y][x] = Y2 . X2^T      v_mfma_f32_16x16x32, A = Y rows (ds_read_b128)
+//            MODE 0: Y1 = K, Y2 = V, X1 = Q, X2 = dO  (T1 = S^T, T2 = dP^T: key on the accumulator row)
+//            MODE 1: Y1 = Q, Y2 = dO, X1 = K, X2 = V  (T1 = S,  T2 = dP : query on the accumulator row)
+//   P  = exp2(T1 * scale*log2e - LSE*log2e)  (LSE from the forward; no running max, no rescale),
+//   dS = P * (T2 - delta)                    (delta from the pre-pass; softmax scale applied in the epilogue)
+//   the accumulators, packed to 16 bits in register order, ARE the B operands of the gradient products
+//   (same trick as the forward's P): out^T[d][x] += Y^T[d][y] . W[y][x], A = Y^T through ds_read_b64_tr_b16:
+//            MODE 0: dQ^T += K^T . dS^T          MODE 1: dV^T += dO^T . P,  dK^T += Q^T . dS
+//   so every streamed tile is ONE LDS image read both by rows and transposed; the XOR swizzle below is
+//   conflict-free for both read kinds (tools/lds_bank_sim.py).
+//   Tiles arrive by LDS-DMA into a 3-stage ring (tile j+2 is issued right after the barrier that publishes
+//   tile j); one barrier per 64-row tile.  MODE 1 also streams the 64 rows' (LSE*log2e, delta) pairs.
+//   Rows past the end of the sequence read as zeros (buffer bounds); the statistics planes are padded with
+//   (+inf, 0) so that such rows give P = 0 without a mask.  Causal: fully masked 32-row blocks are skipped
+//   per wave, the mask is applied only on diagonal blocks, workgroups are launched heaviest first.
+#pragma once
+#include "fa_fwd_kernel.hpp"
+
+namespace fa {
+
+struct BwdParams {
+    const void* x1; const void* x2;     // stationary operands: MODE 0: Q, dO ; MODE 1: K, V
+    const void* y1; const void* y2;     // streamed operands:   MODE 0: K, V  ; MODE 1: Q, dO
+    void* out1; void* out2;             // MODE 0: dQ, unused ; MODE 1: dK, dV
+    const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then delta (0 past S)
+    int B, H, S;
+    int Spad;                           // S rounded up to a multiple of 64
+    int bh;                             // B*H
+    int nxb;                            // stationary blocks per head
+    long long x1_sb, x1_sh, x1_ss;      // element strides (head_dim stride is 1)
+    long long x2_sb, x2_sh, x2_ss;
+    long long y1_sb, y1_sh, y1_ss;
+    long long y2_sb, y2_sh, y2_ss;
+    long long o1_sb, o1_sh, o1_ss;
+    long long o2_sb, o2_sh, o2_ss;
+    float scale;                        // softmax scale
+    float scale_log2;                   // scale * log2(e)
+};
+
+constexpr int kBwdStages = 3;
+template <int MODE> constexpr int bwd_waves() { return MODE == 0 ? 8 : 4; }
+template <int D, int MODE> constexpr int bwd_lds_bytes() { return 2 * kBwdStages * kBN * D * 2 + (MODE == 1 ? kBwdStages * 1024 : 0); }
+
+// 16-byte-chunk swizzle of a streamed tile: serves the 16x16x32 row reads (16 lanes = 16 rows at one chunk)
+// and the transposed reads (a 32-lane half = 8 consecutive rows x 32 bytes) without bank conflicts.
+template <int D> __device__ __forceinline__ int bwd_swz(int row, int ch) {
+    if constexpr (D == 128) return ch ^ ((row & 7) << 1);
+    else return ch ^ (((row >> 1) & 3) << 1);
+}
+
+// pre-pass: delta[row] = sum_d dO[row][d] * O[row][d] (fp32), lse2[row] = LSE[row] * log2(e); padded rows get (+inf, 0).
+// HBM-bound streaming kernel: D/8 lanes per row, 16-byte loads.
+template <class T, int D>
+__global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict__ o, const void* __restrict__ d_o,
+                                                          const float* __restrict__ lse, float* __restrict__ stats,
+                                                          int H, int S, int Spad, int bh,
+                                                          long long o_sb, long long o_sh, long long o_ss,
+                                                          long long g_sb, long long g_sh, long long g_ss)
+{
+    constexpr int LPR = D / 8;                      // lanes per row
+    constexpr int RPB = 256 / LPR;                  // rows per block
+    const int head = blockIdx.y;
+    const int b = head / H, h = head - b * H;
+    const int row = blockIdx.x * RPB + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    if (row >= Spad) return;
+    float acc = 0.f;
+    if (row < S) {
+        const unsigned short* op = reinterpret_cast<const unsigned short*>(o) + b * o_sb + h * o_sh + (long long)row * o_ss + sub * 8;
+        const unsigned short* gp = reinterpret_cast<const unsigned short*>(d_o) + b * g_sb + h * g_sh + (long long)row * g_ss + sub * 8;
+        const u32x4 ov = *reinterpret_cast<const u32x4*>(op);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(gp);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float o0, o1, g0, g1;
+            if constexpr (std::is_same<T, TypeBF16>::value) {
+                o0 = bitcast<float>(ov[w] << 16); o1 = bitcast<float>(ov[w] & 0xffff0000u);
+                g0 = bitcast<float>(gv[w] << 16); g1 = bitcast<float>(gv[w] & 0xffff0000u);
+            } else {
+                const f16x2 oh = bitcast<f16x2>(ov[w]), gh = bitcast<f16x2>(gv[w]);
+                o0 = (float)oh[0]; o1 = (float)oh[1]; g0 = (float)gh[0]; g1 = (float)gh[1];
+            }
+            acc = __builtin_fmaf(o0, g0, acc);
+            acc = __builtin_fmaf(o1, g1, acc);
+        }
+    }
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (sub == 0) {
+        const long long idx = (long long)head * Spad + row;
+        float l2 = INFINITY;
+        if (row < S) {
+            const float l = lse[(long long)head * S + row];
+            l2 = (l == -INFINITY) ? INFINITY : l * 1.4426950408889634f;      // fully masked row: P = 0
+        }
+        stats[idx] = l2;
+        stats[(long long)bh * Spad + idx] = acc;
+    }
+}
+
+template <class T, int D, int MODE, bool CAUSAL>
+__global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const BwdParams p)
+{
+    constexpr int NW = bwd_waves<MODE>();
+    constexpr int XB = NW * 32;                // stationary rows per workgroup
+    constexpr int KS = D / 32;                 // k-steps of the score products
+    constexpr int DT = D / 16;                 // 16-wide head_dim tiles of the gradient accumulators
+    constexpr int ROWB = D * 2;                // bytes per row of an LDS tile
+    constexpr int TILE = kBN * ROWB;           // bytes per streamed tile
+    constexpr int PIECE = 1024;                // bytes one DMA wave-instruction moves
+    constexpr int CPT = TILE / PIECE / NW;     // DMA pieces per wave per tile
+    constexpr int NS = kBwdStages;
+    constexpr int Y2BASE = NS * TILE;
+    constexpr int STBASE = 2 * NS * TILE;      // MODE 1: NS x 1 KiB of row statistics
+    static_assert(CPT >= 1, "tile too small for the workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+
+    // workgroup -> (head, stationary block); blockIdx % 8 = XCD: all blocks of a head share one L2
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int hl = slot / p.nxb;
+    const int t = slot - hl * p.nxb;
+    const int head = hl * 8 + xcd;
+    if (head >= p.bh) return;
+    const int b = head / p.H;
+    const int h = head - b * p.H;
+    const int S = p.S;
+    // heaviest first under the causal mask: the last query block (MODE 0) / the first key block (MODE 1)
+    const int xb = (MODE == 0 && CAUSAL) ? p.nxb - 1 - t : t;
+    const int x0 = xb * XB;                    // first stationary row of the workgroup
+    const int x0w = x0 + wave * 32;            // ... of this wave
+
+    using elem_t = unsigned short;
+    const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh;
+    const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + h * p.x2_sh;
+    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + h * p.y1_sh;
+    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + h * p.y2_sh;
+
+    // ---- streamed range of the workgroup (64-row tiles) and of this wave (32-row blocks)
+    const int nty = (S + kBN - 1) / kBN;
+    int j_begin = 0, j_end = nty;
+    int blk_begin_w = 0, blk_end_w = (S + 31) / 32;      // blocks this wave computes on
+    int blk_mask_lo = 0x7fffffff, blk_mask_hi = -1;      // blocks in [lo, hi] need the causal mask
+    if constexpr (CAUSAL) {
+        if constexpr (MODE == 0) {                        // queries stationary, keys streamed: keys <= query
+            j_end = min(nty, (min(S, x0 + XB) + kBN - 1) / kBN);
+            blk_end_w = (x0w >= S) ? 0 : (min(S, x0w + 32) + 31) / 32;
+            blk_mask_lo = x0w >> 5;                       // first block containing a key > the wave's first query
+            blk_mask_hi = 0x7fffffff;
+        } else {                                          // keys stationary, queries streamed: queries >= key
+            j_begin = min(nty, x0 / kBN);
+            blk_begin_w = x0w >> 5;                       // blocks before it hold only queries < the wave's keys
+            blk_mask_lo = blk_mask_hi = x0w >> 5;         // the diagonal block
+        }
+    }
+    if (x0w >= S) { blk_begin_w = 0; blk_end_w = 0; }     // no stationary rows: staging duty only
+
+    // ---- stationary fragments: lane (li, lg) holds X[x0w + 16 xt + li][32 ks + 8 lg .. +7]
+    u32x4 xf1[2][KS], xf2[2][KS];
+    {
+        const unsigned x1_bytes = (unsigned)(((long long)(S - 1) * p.x1_ss + D) * 2);
+        const unsigned x2_bytes = (unsigned)(((long long)(S - 1) * p.x2_ss + D) * 2);
+        __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x1h), 0, x1_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x2h), 0, x2_bytes, 0x00020000);
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const int xrow = x0w + 16 * xt + li;
+            // rows past the end of the sequence get an offset outside the descriptor: they read as zero
+            const unsigned o1 = (xrow < S) ? (unsigned)((long long)xrow * p.x1_ss * 2 + lg * 16) : 0x80000000u;
+            const unsigned o2 = (xrow < S) ? (unsigned)((long long)xrow * p.x2_ss * 2 + lg * 16) : 0x80000000u;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                xf1[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r1, o1 + ks * 64, 0, 0);
+                xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, o2 + ks * 64, 0, 0);
+            }
+        }
+    }
+    // MODE 0: the statistics belong to the stationary rows (one pair per lane and x tile)
+    float lse_x[2] = {INFINITY, INFINITY}, delta_x[2] = {0.f, 0.f};
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const int xrow = x0w + 16 * xt + li;
+            if (xrow < p.Spad) {
+                lse_x[xt] = p.stats[(long long)head * p.Spad + xrow];
+                delta_x[xt] = p.stats[(long long)(p.bh + head) * p.Spad + xrow];
+            }
+        }
+    }
+
+    // ---- staging by LDS-DMA: piece (wave * CPT + i) of a tile, swizzle applied on the source address
+    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + D) * 2);
+    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + D) * 2);
+    const u32x4 ry1 = make_rsrc(y1h, y1_bytes);
+    const u32x4 ry2 = make_rsrc(y2h, y2_bytes);
+    unsigned g_y1[CPT], g_y2[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int byte = (wave * CPT + i) * PIECE + lane * 16;
+        const int row = byte / ROWB, chp = (byte % ROWB) / 16;
+        g_y1[i] = (unsigned)(row * p.y1_ss * 2 + bwd_swz<D>(row, chp) * 16);
+        g_y2[i] = (unsigned)(row * p.y2_ss * 2 + bwd_swz<D>(row, chp) * 16);
+    }
+    const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
+    const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
+    const unsigned piece_base = lds_base + wave * CPT * PIECE;          // wave-uniform
+    // statistics of a 64-row tile (MODE 1, wave 0): lanes 0-15 fetch LSE*log2e, lanes 16-31 delta, 16 bytes each
+    const u32x4 rst = make_rsrc(p.stats, (unsigned)((long long)2 * p.bh * p.Spad * 4));
+    unsigned g_st = 0x80000000u;
+    if constexpr (MODE == 1) {
+        if (lane < 32) g_st = (unsigned)((((long long)(lane >> 4) * p.bh + head) * p.Spad + (lane & 15) * 4) * 4);
+    }
+    auto issue_tile = [&](int j, int stage) {
+        if constexpr (MODE == 1) {
+            // past the last tile the offset leaves the descriptor only for the delta plane's tail; the LSE lanes
+            // may then read the next head's rows -- harmless, such tiles are never computed on
+            if (wave == 0) dma16(rst, __builtin_amdgcn_readfirstlane(lds_base + STBASE + stage * 1024), g_st + (unsigned)j * (kBN * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            dma16(ry1, __builtin_amdgcn_readfirstlane(piece_base + stage * TILE + i * PIECE), (unsigned)j * y1_tile_stride + g_y1[i]);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            dma16(ry2, __builtin_amdgcn_readfirstlane(piece_base + Y2BASE + stage * TILE + i * PIECE), (unsigned)j * y2_tile_stride + g_y2[i]);
+    };
+
+    // ---- LDS read addresses (stage 0, block 0)
+    unsigned ra[KS];           // row reads: lane (li, lg) reads row li (+16 yt + 32 blk), chunk 4 ks + lg
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ra[ks] = lds_base + li * ROWB + bwd_swz<D>(li, 4 * ks + lg) * 16;
+    unsigned ta[DT];           // transposed reads: lane 4 qq + pp of a 16-lane group supplies row 4 lg + qq, columns 16 dt + 4 pp .. +3
+    {
+        const int qq = li >> 2, pp = li & 3;
+        const int row = 4 * lg + qq;                  // + 16 a + 32 blk: multiples of 16 rows, swizzle-neutral
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ta[dt] = lds_base + row * ROWB + bwd_swz<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+    }
+
+    f32x4 acc1[DT][2];         // MODE 0: dQ^T ; MODE 1: dK^T   [head_dim tile][x tile]
+    f32x4 acc2[MODE == 1 ? DT : 1][2];   // MODE 1: dV^T
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            acc1[dt][xt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == 1) acc2[dt][xt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const float c = p.scale_log2;
+
+    // ---- one 32-row block of the tile in ring stage `stage`
+    auto compute_block = [&] __device__ (auto mask_c, int stage, int blk, int y0) {
+        constexpr bool MASK = decltype(mask_c)::value;
+        const unsigned so = stage * TILE + blk * 32 * ROWB;
+        f32x4 t1[2][2], t2[2][2];                     // [y tile][x tile]
+#pragma unroll
+        for (int yt = 0; yt < 2; ++yt) {
+            t1[yt][0] = t1[yt][1] = t2[yt][0] = t2[yt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 a1 = lds_read_b128(ra[ks] + so + yt * 16 * ROWB);
+                const u32x4 a2 = lds_read_b128(ra[ks] + Y2BASE + so + yt * 16 * ROWB);
+#pragma unroll
+                for (int xt = 0; xt < 2; ++xt) {
+                    t1[yt][xt] = T::mfma16(a1, xf1[xt][ks], t1[yt][xt]);
+                    t2[yt][xt] = T::mfma16(a2, xf2[xt][ks], t2[yt][xt]);
+                }
+            }
+        }
+        // row statistics of the streamed rows (MODE 1): rows 16 yt + 4 lg + 0..3 of the block
+        f32x4 lse_y[2], delta_y[2];
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int yt = 0; yt < 2; ++yt) {
+                const unsigned sa = lds_base + STBASE + stage * 1024 + (blk * 32 + 16 * yt + 4 * lg) * 4;
+                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sa));
+                delta_y[yt] = bitcast<f32x4>(lds_read_b128(sa + 256));
+            }
+        }
+        u32x4 pw[2], dsw[2];                           // packed P and dS: B operands, element 4 yt + e <-> y = 16 yt + 4 lg + e
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const int xrow = x0w + 16 * xt + li;
+#pragma unroll
+            for (int yt = 0; yt < 2; ++yt) {
+                float pv[4], dv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float l2 = (MODE == 0) ? lse_x[xt] : lse_y[yt][e];
+                    const float dl = (MODE == 0) ? delta_x[xt] : delta_y[yt][e];
+                    float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[yt][xt][e], c, -l2));
+                    if constexpr (MASK) {
+                        const int yrow = y0 + 16 * yt + 4 * lg + e;
+                        const bool dead = (MODE == 0) ? (yrow > xrow) : (xrow > yrow);     // key > query
+                        if (dead) pe = 0.f;
+                    }
+                    pv[e] = pe;
+                    dv[e] = pe * (t2[yt][xt][e] - dl);
+                }
+                if constexpr (MODE == 1) {
+                    pw[xt][2 * yt] = T::pack2(pv[0], pv[1]);
+                    pw[xt][2 * yt + 1] = T::pack2(pv[2], pv[3]);
+                }
+                dsw[xt][2 * yt] = T::pack2(dv[0], dv[1]);
+                dsw[xt][2 * yt + 1] = T::pack2(dv[2], dv[3]);
+            }
+        }
+        // gradient products: A = Y^T fragments through the transposed read (rows 4 lg .. +3 and 16 + 4 lg .. +3 of the block)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const u32x2 lo1 = lds_read_tr16_b64(ta[dt] + so);
+            const u32x2 hi1 = lds_read_tr16_b64(ta[dt] + so + 16 * ROWB);
+            const u32x4 a1 = {lo1[0], lo1[1], hi1[0], hi1[1]};
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt) acc1[dt][xt] = T::mfma16(a1, dsw[xt], acc1[dt][xt]);
+            if constexpr (MODE == 1) {
+                const u32x2 lo2 = lds_read_tr16_b64(ta[dt] + Y2BASE + so);
+                const u32x2 hi2 = lds_read_tr16_b64(ta[dt] + Y2BASE + so + 16 * ROWB);
+                const u32x4 a2 = {lo2[0], lo2[1], hi2[0], hi2[1]};
+#pragma unroll
+                for (int xt = 0; xt < 2; ++xt) acc2[dt][xt] = T::mfma16(a2, pw[xt], acc2[dt][xt]);
+            }
+        }
+    };
+
+    // ---- main loop: tile j lives in ring stage (j - j_begin) % NS; tile j + 2 is issued behind barrier j
+    constexpr int OPS = 2 * CPT;                      // DMA instructions per tile and wave (wave 0 of MODE 1: one more, issued first)
+    if (j_begin < j_end) {
+        issue_tile(j_begin, 0);
+        issue_tile(j_begin + 1, 1);
+        int stage = 0;
+        for (int j = j_begin; j < j_end; ++j) {
+            dma_wait<OPS>();                          // this wave's pieces of tile j have landed ...
+            __syncthreads();                          // ... every wave's are visible, and tile j-1 is no longer read
+            issue_tile(j + 2, stage == 0 ? 2 : stage - 1);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int bi = 2 * j + blk;
+                if (bi >= blk_begin_w && bi < blk_end_w) {
+                    if (CAUSAL && bi >= blk_mask_lo && bi <= blk_mask_hi) compute_block(std::true_type{}, stage, blk, bi * 32);
+                    else compute_block(std::false_type{}, stage, blk, bi * 32);
+                }
+            }
+            stage = (stage == NS - 1) ? 0 : stage + 1;
+        }
+        dma_wait<0>();                                // no DMA may still be writing LDS when the workgroup retires
+    }
+
+    // ---- epilogue: out[x][16 dt + 4 lg + 0..3] = acc[dt][xt] * mult, 16-byte stores through v_permlane16_swap pairs
+    auto store_out = [&] __device__ (f32x4 (&acc)[DT][2], void* out, long long sb, long long sh, long long ss, float mult) {
+        elem_t* oh = reinterpret_cast<elem_t*>(out) + b * sb + h * sh;
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const int xrow = x0w + 16 * xt + li;
+            elem_t* orow = oh + (long long)xrow * ss;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt += 2) {
+                const f32x4 oa = acc[dt][xt], ob = acc[dt + 1][xt];
+                unsigned a0 = T::pack2(oa[0] * mult, oa[1] * mult), a1 = T::pack2(oa[2] * mult, oa[3] * mult);
+                unsigned b0 = T::pack2(ob[0] * mult, ob[1] * mult), b1 = T::pack2(ob[2] * mult, ob[3] * mult);
+                auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+                if (xrow < S) {
+                    const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+                    *reinterpret_cast<u32x4*>(orow + col) = outv;
+                }
+            }
+        }
+    };
+    store_out(acc1, p.out1, p.o1_sb, p.o1_sh, p.o1_ss, p.scale);
+    if constexpr (MODE == 1) store_out(acc2, p.out2, p.o2_sb, p.o2_sh, p.o2_ss, 1.0f);
+}
+
+}  // namespace fa

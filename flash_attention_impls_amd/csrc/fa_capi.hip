@@ -15,6 +15,7 @@
 #include <mutex>
 
 #include "../../include/fa_mi355.h"
+#include "fa_capi_common.hpp"
 #include "fa_fwd_kernel.hpp"
 #include "fa_fwd_kernel16.hpp"
 
@@ -28,16 +29,9 @@ namespace {
 constexpr int kQB = FA_QB;
 constexpr int kThreads = fa::threads_per_wg<kQB>();
 
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
+using fa_capi::fail;
+using fa_capi::g_err;
+using fa_capi::set_strides;
 
 template <class T, int D, bool CAUSAL>
 int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
@@ -123,13 +117,6 @@ int grid_for(int B, int H, int S, bool causal)
     const long long per_head = causal ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
     const long long g = ((bh + 7) / 8) * 8 * per_head;         // heads padded to a multiple of 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
-}
-
-bool set_strides(const int64_t* s, int H, int S, int D, long long& sb, long long& sh, long long& ss)
-{
-    if (s == nullptr) { ss = D; sh = (long long)S * D; sb = (long long)H * S * D; return true; }
-    sb = s[0]; sh = s[1]; ss = s[2];
-    return sb >= 0 && sh >= 0 && ss >= D;
 }
 
 }  // namespace

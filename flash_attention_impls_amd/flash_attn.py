@@ -11,6 +11,8 @@ Mirrors, for the forward path only:
 The north-star spells the entry ``flash_attn``; the reference spells it ``flash_attention``.
 Both names are exported and are the same function.
 
+``FlashAttnFn`` mirrors ``_FlashAttnFn`` including ``backward`` (FA2-triton.py:207-237).
+
 There is NO CPU fallback: CPU tensors raise (as the reference's ``assert q.is_cuda`` does) and a
 missing HIP library raises ``RuntimeError``.
 """
@@ -65,6 +67,11 @@ def _declare(lib):
                                c.POINTER(c.c_int64), c.POINTER(c.c_int64),
                                c.c_int, c.c_float, c.POINTER(c.c_float),
                                c.c_void_p, c.c_size_t, c.c_void_p]
+    lib.fa_bwd_workspace_bytes.restype = c.c_size_t
+    lib.fa_bwd_workspace_bytes.argtypes = [c.c_int, c.c_int, c.c_int]
+    lib.fa_bwd.restype = c.c_int
+    lib.fa_bwd.argtypes = [c.c_void_p] * 9 + [c.c_int] * 4 + [c.POINTER(c.c_int64)] * 8 + \
+        [c.c_int, c.c_int, c.c_float, c.c_void_p, c.c_size_t, c.c_void_p]
     lib.fa_fwd_dispatch.restype = c.c_int
     lib.fa_fwd_dispatch.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                     c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p]
@@ -150,6 +157,76 @@ def check_args(q, k, v) -> None:
         raise FlashAttnArgumentError(f"head_dim must satisfy D % 16 == 0 and D <= 128; got {D}")
 
 
+def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
+    """Launch the forward on kernel-ready tensors (head_dim 64 or 128).  Returns (o, lse or None)."""
+    code = _dtype_code(q.dtype)
+    B, H, N, D = q.shape
+    out_dtype = torch.bfloat16 if code == FA_DTYPE_FP8_E4M3 else q.dtype
+    o = torch.empty((B, H, N, D), dtype=out_dtype, device=q.device)        # FA2-triton.py:179
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if want_lse else None
+    if B * H * N == 0:
+        return o, lse
+    dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        lse_ptr = lse.data_ptr() if lse is not None else None
+        if code == FA_DTYPE_FP8_E4M3:
+            nbytes = lib.fa_fp8_workspace_bytes(B, H, N, D)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            rc = lib.fa_fwd_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
+                                B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                                1 if causal else 0, scale, dsc, ws.data_ptr(), nbytes, stream)
+        else:
+            rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
+                            B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                            code, 1 if causal else 0, scale, dsc, stream)
+    if rc != 0:
+        raise RuntimeError(f"fa_fwd failed ({rc}): {lib.fa_last_error().decode()}")
+    return o, lse
+
+
+def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
+    """Launch the backward (pre-pass + dQ kernel + dK/dV kernel).  Returns (dq, dk, dv), each written once."""
+    code = _dtype_code(q.dtype)
+    B, H, N, D = q.shape
+    dq, dk, dv = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)     # contiguous, like o
+    if B * H * N == 0:
+        return dq, dk, dv
+    do = _kernel_ready(do.to(q.dtype))
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        nbytes = lib.fa_bwd_workspace_bytes(B, H, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        rc = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, N, D,
+                        _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(do),
+                        _strides3(dq), _strides3(dk), _strides3(dv),
+                        code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
+    if rc != 0:
+        raise RuntimeError(f"fa_bwd failed ({rc}): {lib.fa_last_error().decode()}")
+    return dq, dk, dv
+
+
+class FlashAttnFn(torch.autograd.Function):
+    """Differentiable forward, mirroring ``_FlashAttnFn`` (FA2-triton.py:173-237): forward saves q, k, v and
+    the softmax statistics (here O and LSE = m + ln l instead of m, l), backward recomputes P."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool, scale: float):
+        o, lse = _fwd_raw(load_library(), q, k, v, causal, scale, None, True)
+        ctx.save_for_backward(q, k, v, o, lse)                # FA2-triton.py:203
+        ctx.causal = causal                                   # :204
+        ctx.scale = scale
+        ctx.mark_non_differentiable(lse)
+        return o, lse
+
+    @staticmethod
+    def backward(ctx, do, _dlse):
+        q, k, v, o, lse = ctx.saved_tensors                   # :209
+        dq, dk, dv = _bwd_raw(load_library(), q, k, v, o, lse, do, ctx.causal, ctx.scale)
+        return dq, dk, dv, None, None                         # :237
+
+
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
                softmax_scale: float | None = None, return_lse: bool = False,
                descale: tuple[float, float, float] | None = None):
@@ -158,12 +235,17 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     Returns O with q's dtype (fp32 inputs are computed in fp16 and cast back, like the
     reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural
     log-sum-exp of the scaled scores (the reference keeps m and l instead: lse = m + ln l).
+    Differentiable like the reference's entry point: when autograd is recording and an input requires
+    grad, the HIP backward kernels produce dq, dk, dv (bf16 / fp16 / fp32-via-fp16 inputs).
     """
     check_args(q, k, v)
     orig_dtype = q.dtype
+    needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
     if q.dtype == torch.float32:                         # FA2-triton.py:241-243
         q, k, v = q.half(), k.half(), v.half()
     code = _dtype_code(q.dtype)
+    if needs_grad and code == FA_DTYPE_FP8_E4M3:
+        raise FlashAttnArgumentError("float8 inputs are forward-only (no backward kernel)")
     lib = load_library()
     B, H, N, D_in = q.shape
     if softmax_scale is None:
@@ -181,27 +263,10 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     if not lib.fa_supported(code, D):
         raise FlashAttnArgumentError(f"no gfx950 kernel compiled for dtype={q.dtype}, head_dim={D}")
     q, k, v = _kernel_ready(q), _kernel_ready(k), _kernel_ready(v)
-    out_dtype = torch.bfloat16 if code == FA_DTYPE_FP8_E4M3 else q.dtype
-    o = torch.empty((B, H, N, D), dtype=out_dtype, device=q.device)        # FA2-triton.py:179
-    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
-    if B * H * N > 0:
-        scale = float(softmax_scale)
-        dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
-        with torch.cuda.device(q.device):
-            stream = torch.cuda.current_stream().cuda_stream
-            lse_ptr = lse.data_ptr() if lse is not None else None
-            if code == FA_DTYPE_FP8_E4M3:
-                nbytes = lib.fa_fp8_workspace_bytes(B, H, N, D)
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-                rc = lib.fa_fwd_fp8(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
-                                    B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
-                                    1 if causal else 0, scale, dsc, ws.data_ptr(), nbytes, stream)
-            else:
-                rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
-                                B, H, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
-                                code, 1 if causal else 0, scale, dsc, stream)
-        if rc != 0:
-            raise RuntimeError(f"fa_fwd failed ({rc}): {lib.fa_last_error().decode()}")
+    if needs_grad:
+        o, lse = FlashAttnFn.apply(q, k, v, bool(causal), float(softmax_scale))
+    else:
+        o, lse = _fwd_raw(lib, q, k, v, bool(causal), float(softmax_scale), descale, return_lse)
     if D != D_in:
         o = o[..., :D_in].contiguous()
     if orig_dtype == torch.float32:

@@ -15,6 +15,9 @@
  *   fa_supported           <- the head_dim switch of that dispatcher (:530-543) and the
  *                             asserts of FA2-triton.py:176-178
  *   fa_last_error          <- fprintf(stderr, ...) at flash_attn_cutlass.cu:510-514,540-542
+ *   fa_bwd                 <- _FlashAttnFn.backward + _bwd_kernel launch
+ *                             code/triton_fa2/FA2-triton.py:207-237 (q,k,v, the forward's statistics and dO in;
+ *                             dQ,dK,dV out -- written once each, no zero-fill and no atomics needed)
  *
  * Conventions
  *   - all tensor pointers are DEVICE pointers owned by the caller; the library never
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 100          /* 0.1.0 */
+#define FA_VERSION 110          /* 0.1.1: + backward */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -103,6 +106,29 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
 int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,
                     int batch_size, int num_heads, int seq_len, int head_dim,
                     int dtype, void* stream);
+
+/*
+ * Attention backward:  given dO, the forward's inputs, its output O and its LSE, writes
+ *   dV = P^T dO,  dQ = scale * dS K,  dK = scale * dS^T Q,   P = exp(scale*Q K^T [masked] - LSE),
+ *   dS = P o (dO V^T - delta),  delta = rowsum(dO o O)
+ * (the recompute backward of FA2-triton.py:98-170 with the softmax Jacobian in its correct form; the
+ * reference's :160-161 is defective and is not reproduced -- see DESIGN.md §2).
+ *   q,k,v,o,d_o : [B,H,S,D] inputs of element type dtype (FA_DTYPE_BF16 / FA_DTYPE_FP16), strides as for fa_fwd
+ *   lse         : contiguous [B,H,S] fp32, as written by fa_fwd (natural log-sum-exp of the scaled scores)
+ *   dq,dk,dv    : [B,H,S,D] outputs of element type dtype; every element is written (no need to zero them)
+ *   causal, softmax_scale : must equal the forward call's
+ *   workspace   : device buffer of at least fa_bwd_workspace_bytes(B,H,S) bytes, 16-byte aligned
+ * Three launches on `stream`: row statistics pre-pass, dQ kernel, dK/dV kernel.  Deterministic (no atomics).
+ */
+size_t fa_bwd_workspace_bytes(int B, int H, int S);
+int fa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+           void* dq, void* dk, void* dv,
+           int B, int H, int S, int D,
+           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+           const int64_t* o_strides, const int64_t* do_strides,
+           const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
+           int dtype, int causal, float softmax_scale,
+           void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Launch geometry that fa_fwd would use (for benches / profilers): writes grid size,

@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             "fa_fwd_launch_info", "fa_fwd_fp8", "fa_fp8_workspace_bytes"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
-    assert lib.fa_version() == 100
+    assert lib.fa_version() == 110
     assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
 
 
