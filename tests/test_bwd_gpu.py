@@ -1,0 +1,247 @@
+"""GPU parity tests of the backward: HIP path (autograd Function -> ctypes -> fa_bwd -> pre-pass + dQ kernel +
+dK/dV kernel) vs the oracle.
+
+Tolerance (stated): |g - ref| <= tol * max(1, max|ref|) per gradient tensor with tol = 1.6e-2 for bf16 and 2e-3
+for fp16 (the forward's tolerances), plus a relative Frobenius bound of 6e-3 / 1e-3 -- ref = the
+fixtures' autograd-through-sdpa_reference gradients, or the float64 closed form of the dtype-rounded inputs.
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL, c_oracle_bwd, golden_bwd_names, golden_torch, load_golden
+from oracle import attn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import flash_attention_impls_amd as fa  # noqa: E402
+
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+REL_FRO = {"bf16": 6e-3, "fp16": 1e-3, "fp32": 1e-3}
+
+
+def rand4(B, H, S, D, dtype, seed=0, mul=1.0, device="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(B, H, S, D, generator=g) * mul).to(dtype).to(device) for _ in range(4)]
+
+
+def hip_grads(q, k, v, do, causal, **kw):
+    qg, kg, vg = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+    o = fa.flash_attn(qg, kg, vg, causal, **kw)
+    o.backward(do)
+    torch.cuda.synchronize()
+    return o.detach(), qg.grad, kg.grad, vg.grad
+
+
+def assert_grad_close(got, ref, dt, what):
+    got = got.float().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, what
+    assert np.isfinite(got).all(), f"non-finite values in {what}"
+    if ref.size == 0:
+        return
+    err = np.abs(got - ref).max()
+    bound = TOL[dt] * max(1.0, np.abs(ref).max())
+    assert err <= bound, f"{what}: max|g-ref|={err:.4e} > {bound:.4e}"
+    nrm = np.linalg.norm(ref)
+    if nrm > 0:
+        rel = np.linalg.norm(got - ref) / nrm
+        assert rel <= REL_FRO[dt], f"{what}: relative Frobenius error {rel:.3e} > {REL_FRO[dt]:.1e}"
+
+
+# ------------------------------------------------------------------ golden vectors (from the reference)
+@pytest.mark.parametrize("name", golden_bwd_names())
+def test_bwd_golden_vectors(name):
+    assert fa.load_library().fa_version() == 110
+    d = load_golden(name)
+    q, k, v, do = [golden_torch(d, n, "cuda") for n in ("q", "k", "v", "do")]
+    o, dq, dk, dv = hip_grads(q, k, v, do, bool(d["causal"]))
+    assert dq.dtype == q.dtype and dq.shape == q.shape
+    for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert_grad_close(got, d[key], d["dtype"], f"{name}:{key}")
+    if "dv_kernel" in d:
+        # the reference's own Triton kernel (interpreted): its dV is right (fp16 atomics), and ours agrees with it
+        assert np.abs(dv.float().cpu().numpy() - d["dv_kernel"].astype(np.float32)).max() < 6e-3
+
+
+# ------------------------------------------------------------------ shape grid vs the float64 oracle
+GRID = [
+    # B, H, S, D, dtype, causal
+    (1, 1, 64, 128, "bf16", False), (1, 1, 64, 128, "bf16", True),
+    (2, 2, 128, 64, "bf16", True), (1, 3, 129, 64, "fp16", False),
+    (1, 2, 255, 128, "bf16", True), (1, 2, 257, 128, "fp16", True),
+    (2, 1, 383, 128, "bf16", False), (1, 5, 96, 64, "bf16", True),
+    (1, 1, 31, 128, "fp16", True), (1, 1, 33, 64, "bf16", False),
+    (1, 2, 512, 128, "bf16", True), (1, 9, 320, 64, "fp16", False),
+    (3, 1, 65, 128, "bf16", True), (1, 1, 2, 64, "fp16", True),
+]
+
+
+@pytest.mark.parametrize("B,H,S,D,dt,causal", GRID)
+def test_bwd_shape_grid(B, H, S, D, dt, causal):
+    q, k, v, do = rand4(B, H, S, D, DT[dt], seed=S * 7 + D)
+    _, dq, dk, dv = hip_grads(q, k, v, do, causal)
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=causal)
+    for got, r, key in ((dq, ref[0], "dq"), (dk, ref[1], "dk"), (dv, ref[2], "dv")):
+        assert_grad_close(got, r, dt, f"{(B, H, S, D, dt, causal)}:{key}")
+
+
+def test_bwd_matches_c_oracle(oracle_clib):
+    q, k, v, do = rand4(1, 2, 160, 64, torch.bfloat16, seed=5)
+    _, dq, dk, dv = hip_grads(q, k, v, do, True)
+    ref = c_oracle_bwd(oracle_clib, *[t.float().cpu().numpy() for t in (q, k, v, do)], True)
+    for got, r, key in zip((dq, dk, dv), ref, ("dq", "dk", "dv")):
+        assert_grad_close(got, r, "bf16", key)
+
+
+# ------------------------------------------------------------------ API behaviour (FA2-triton.py:207-244)
+def test_bwd_fp32_inputs_round_trip_through_fp16():
+    """fp32 tensors are computed in fp16 and cast back (FA2-triton.py:241-244); grads come back as fp32."""
+    q, k, v, do = rand4(1, 2, 100, 64, torch.float32, seed=9)
+    o, dq, dk, dv = hip_grads(q, k, v, do, True)
+    assert o.dtype == torch.float32 and dq.dtype == torch.float32
+    ref = orc.naive_attention_bwd_f64(*[t.half().float().cpu().numpy() for t in (q, k, v)], do.cpu().numpy(), causal=True)
+    for got, r, key in ((dq, ref[0], "dq"), (dk, ref[1], "dk"), (dv, ref[2], "dv")):
+        assert_grad_close(got, r, "fp32", key)
+
+
+@pytest.mark.parametrize("D", [16, 48, 96])
+def test_bwd_padded_head_dims(D):
+    """D % 16 == 0, D <= 128 (FA2-triton.py:178): zero-padded to a compiled size on the host, scale 1/sqrt(D)."""
+    q, k, v, do = rand4(1, 2, 130, D, torch.bfloat16, seed=D)
+    _, dq, dk, dv = hip_grads(q, k, v, do, True)
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=True)
+    for got, r, key in ((dq, ref[0], "dq"), (dk, ref[1], "dk"), (dv, ref[2], "dv")):
+        assert_grad_close(got, r, "bf16", f"D={D}:{key}")
+
+
+def test_bwd_sum_loss_and_strided_inputs():
+    """The reference harness differentiates out.sum() (FA2-triton.py:357-372): dO arrives as a stride-0
+    expansion; q/k/v given as (B,S,H,D) permuted views."""
+    B, H, S, D = 2, 3, 200, 128
+    g = torch.Generator().manual_seed(3)
+    base = [torch.randn(B, S, H, D, generator=g).to(torch.bfloat16).cuda() for _ in range(3)]
+    leaves = [t.clone().requires_grad_(True) for t in base]
+    q, k, v = [t.permute(0, 2, 1, 3) for t in leaves]
+    fa.flash_attn(q, k, v, True).sum().backward()
+    ref = orc.naive_attention_bwd_f64(*[t.permute(0, 2, 1, 3).float().cpu().numpy() for t in base],
+                                      np.ones((B, H, S, D)), causal=True)
+    for leaf, r, key in zip(leaves, ref[:3], ("dq", "dk", "dv")):
+        assert leaf.grad.shape == (B, S, H, D)
+        assert_grad_close(leaf.grad.permute(0, 2, 1, 3), r, "bf16", key)
+
+
+def test_bwd_custom_scale_and_partial_requires_grad():
+    q, k, v, do = rand4(1, 2, 192, 64, torch.float16, seed=11)
+    qg = q.clone().requires_grad_(True)
+    o = fa.flash_attn(qg, k, v, False, softmax_scale=0.2)
+    o.backward(do)
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=False, scale=0.2)
+    assert_grad_close(qg.grad, ref[0], "fp16", "dq")
+    assert k.grad is None and v.grad is None
+
+
+def test_bwd_return_lse_is_not_differentiable_and_no_grad_path_unchanged():
+    q, k, v, do = rand4(1, 1, 128, 128, torch.bfloat16, seed=2)
+    qg = q.clone().requires_grad_(True)
+    o, lse = fa.flash_attn(qg, k, v, True, return_lse=True)
+    assert o.requires_grad and not lse.requires_grad
+    with torch.no_grad():
+        o2, lse2 = fa.flash_attn(qg, k, v, True, return_lse=True)
+    assert torch.equal(o.detach(), o2) and torch.equal(lse, lse2)
+    assert not o2.requires_grad
+
+
+def test_bwd_fp8_is_forward_only():
+    q = torch.randn(1, 1, 64, 128, device="cuda").to(torch.float8_e4m3fn)
+    with pytest.raises(AssertionError):
+        qq = q.view(torch.uint8).view(torch.float8_e4m3fn)
+        qq.requires_grad_(True)
+        fa.flash_attn(qq, q, q, descale=(1.0, 1.0, 1.0))
+
+
+def test_bwd_empty():
+    q = torch.empty(0, 2, 16, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    o = fa.flash_attn(q, q, q, True)
+    o.sum().backward()
+    assert q.grad.shape == q.shape
+
+
+# ------------------------------------------------------------------ size-independent properties at full sizes
+def test_bwd_bitwise_deterministic():
+    """No atomics anywhere: two launches give identical bits (the reference's fp16 atomics do not)."""
+    q, k, v, do = rand4(2, 4, 1024, 128, torch.bfloat16, seed=1)
+    a = hip_grads(q, k, v, do, True)
+    b = hip_grads(q, k, v, do, True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_bwd_linearity_in_dO(causal):
+    """The backward is linear in dO: grads(dO1 + dO2) = grads(dO1) + grads(dO2) up to output rounding."""
+    q, k, v, do1 = rand4(1, 4, 2048, 128, torch.bfloat16, seed=4)
+    do2 = torch.randn_like(do1.float()).to(torch.bfloat16)
+    g1 = hip_grads(q, k, v, do1, causal)[1:]
+    g2 = hip_grads(q, k, v, do2, causal)[1:]
+    g12 = hip_grads(q, k, v, (do1.float() + do2.float()).to(torch.bfloat16), causal)[1:]
+    for a, b, c, key in zip(g1, g2, g12, ("dq", "dk", "dv")):
+        s = a.float() + b.float()
+        rel = float((c.float() - s).norm() / s.norm())
+        assert rel < 8e-3, (key, rel)
+
+
+def test_bwd_dv_column_sums():
+    """sum_j dV[j] = sum_i dO[i] (rows of P sum to one): checks the whole P^T dO product at cfg3's head shape."""
+    q, k, v, do = rand4(1, 2, 4096, 128, torch.bfloat16, seed=6)
+    _, dq, dk, dv = hip_grads(q, k, v, do, True)
+    lhs = dv.float().sum(dim=2)
+    rhs = do.float().sum(dim=2)
+    assert float((lhs - rhs).abs().max()) <= 2e-2 * max(1.0, float(rhs.abs().max()))
+    # sum_j dK[j] . K[j] == sum_i dQ[i] . Q[i]  (both equal scale * sum_ij dS_ij S_ij / scale)
+    a = (dk.float() * k.float()).sum(dim=(2, 3))
+    b = (dq.float() * q.float()).sum(dim=(2, 3))
+    assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(b.abs().max()))
+
+
+def test_bwd_cfg3_slice_against_gpu_sdpa():
+    """BASELINE cfg3 head shape (S=4096, D=128, bf16, causal), two heads, against autograd through fp32 SDPA
+    on the box (the oracle at this size would take minutes in numpy)."""
+    import torch.nn.functional as F
+    q, k, v, do = rand4(1, 2, 4096, 128, torch.bfloat16, seed=8)
+    _, dq, dk, dv = hip_grads(q, k, v, do, True)
+    qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+    F.scaled_dot_product_attention(qf, kf, vf, is_causal=True, scale=1 / math.sqrt(128)).backward(do.float())
+    for got, r, key in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+        assert_grad_close(got, r.cpu().numpy(), "bf16", key)
+
+
+# ------------------------------------------------------------------ raw C ABI
+def test_capi_bwd_errors_and_direct_call():
+    lib = fa.load_library()
+    B, H, S, D = 1, 2, 96, 64
+    q, k, v, do = rand4(B, H, S, D, torch.float16, seed=12)
+    o, lse = fa.flash_attn(q, k, v, True, return_lse=True)
+    dq, dk, dv = [torch.empty_like(q) for _ in range(3)]
+    n = lib.fa_bwd_workspace_bytes(B, H, S)
+    assert n == 2 * B * H * 128 * 4
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    null = None
+    stream = torch.cuda.current_stream().cuda_stream
+    args = [t.data_ptr() for t in (q, k, v, o, do, lse, dq, dk, dv)]
+    rc = lib.fa_bwd(*args, B, H, S, D, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream)
+    assert rc == 0, lib.fa_last_error()
+    torch.cuda.synchronize()
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=True)
+    for got, r, key in ((dq, ref[0], "dq"), (dk, ref[1], "dk"), (dv, ref[2], "dv")):
+        assert_grad_close(got, r, "fp16", key)
+    assert lib.fa_bwd(*args, B, H, S, D, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n - 1, stream) == -3
+    assert b"workspace" in lib.fa_last_error()
+    assert lib.fa_bwd(*args, B, H, S, D, *([null] * 8), 2, 1, 0.0, ws.data_ptr(), n, stream) == -1
+    assert lib.fa_bwd(*args, B, H, S, 96, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream) == -2
+    bad = list(args)
+    bad[4] = null
+    assert lib.fa_bwd(*bad, B, H, S, D, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream) == -5

@@ -154,3 +154,39 @@ def test_flop_and_byte_model():
     assert attn_flops(8, 32, 4096, 128, True) == pytest.approx(1.0995e12, rel=1e-4)
     assert attn_flops(1, 32, 8192, 128, False) == pytest.approx(4 * 32 * 8192 ** 2 * 128)
     assert attn_bytes(8, 32, 4096, 128) == pytest.approx(1073.7e6 + 4.19e6, rel=1e-3)
+
+
+def test_capi_bwd_error_codes_without_gpu():
+    """fa_bwd validates before launching anything: safe on CPU."""
+    lib = fa.load_library()
+    null = None
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    nine = [p] * 9
+    n = lib.fa_bwd_workspace_bytes(1, 1, 8)
+    assert n == 2 * 64 * 4 and lib.fa_bwd_workspace_bytes(0, 1, 8) == 0
+    assert lib.fa_bwd_workspace_bytes(8, 32, 4096) == 2 * 8 * 32 * 4096 * 4
+    assert lib.fa_bwd(*nine, 1, 1, 8, 128, *([null] * 8), 2, 0, 0.0, p, n, null) == -1      # fp8: forward only
+    assert b"bf16 and fp16" in lib.fa_last_error()
+    assert lib.fa_bwd(*nine, 1, 1, 8, 96, *([null] * 8), 0, 0, 0.0, p, n, null) == -2
+    assert lib.fa_bwd(*nine, 1, -1, 8, 128, *([null] * 8), 0, 0, 0.0, p, n, null) == -3
+    assert lib.fa_bwd(*nine, 1, 1, 8, 128, *([null] * 8), 0, 0, 0.0, p, n - 4, null) == -3
+    assert lib.fa_bwd(*([p] * 8 + [null]), 1, 1, 8, 128, *([null] * 8), 0, 0, 0.0, p, n, null) == -5
+    assert lib.fa_bwd(*nine, 1, 1, 8, 128, *([null] * 8), 0, 0, 0.0, null, n, null) == -5
+    bad = (ctypes.c_int64 * 3)(8 * 128, 8 * 128, 100)                                       # seq stride < head_dim
+    assert lib.fa_bwd(*nine, 1, 1, 8, 128, bad, *([null] * 7), 0, 0, 0.0, p, n, null) == -4
+    odd = (ctypes.c_int64 * 3)(8 * 132, 8 * 132, 132)                                       # rows not 16-byte aligned
+    assert lib.fa_bwd(*nine, 1, 1, 8, 128, odd, *([null] * 7), 0, 0, 0.0, p, n, null) == -4
+    assert lib.fa_bwd(*nine, 0, 1, 8, 128, *([null] * 8), 0, 0, 0.0, null, 0, null) == 0      # empty problem: no-op
+
+
+def test_autograd_function_mirrors_reference_class():
+    """FlashAttnFn <-> _FlashAttnFn (FA2-triton.py:173-237): forward(ctx,q,k,v,causal,...) / backward(ctx,do)."""
+    import inspect
+    assert issubclass(fa.FlashAttnFn, torch.autograd.Function)
+    assert list(inspect.signature(fa.FlashAttnFn.forward).parameters)[:5] == ["ctx", "q", "k", "v", "causal"]
+    assert list(inspect.signature(fa.FlashAttnFn.backward).parameters)[:2] == ["ctx", "do"]
+    # CPU tensors that require grad still fail loudly (no fallback)
+    q = torch.randn(1, 1, 8, 64, requires_grad=True)
+    with pytest.raises(AssertionError):
+        fa.flash_attn(q, q, q)
