@@ -24,8 +24,10 @@
 //            MODE 0: dQ^T += K^T . dS^T          MODE 1: dV^T += dO^T . P,  dK^T += Q^T . dS
 //   so every streamed tile is ONE LDS image read both by rows and transposed; the XOR swizzle below is
 //   conflict-free for both read kinds (tools/lds_bank_sim.py).
-//   Tiles arrive by LDS-DMA into a 3-stage ring (tile j+2 is issued right after the barrier that publishes
-//   tile j); one barrier per 64-row tile.  MODE 1 also streams the 64 rows' (LSE*log2e, delta) pairs.
+//   Tiles arrive by LDS-DMA into a 3-stage (MODE 0) / 4-stage (MODE 1) ring (tile j+2 is issued right after the
+//   barrier that publishes tile j); one barrier per 64-row tile.  MODE 0 runs two waves per SIMD and lets the
+//   hardware interleave them; MODE 1 (one wave per SIMD) software-pipelines the 32-row blocks: scores(i) and
+//   grads(i-2) are issued around the softmax of block i-1.  MODE 1 also streams the 64 rows' (LSE*log2e, delta) pairs.
 //   Rows past the end of the sequence read as zeros (buffer bounds); the statistics planes are padded with
 //   (+inf, 0) so that such rows give P = 0 without a mask.  Causal: fully masked 32-row blocks are skipped
 //   per wave, the mask is applied only on diagonal blocks, workgroups are launched heaviest first.
@@ -53,9 +55,9 @@ struct BwdParams {
     float scale_log2;                   // scale * log2(e)
 };
 
-constexpr int kBwdStages = 3;
 template <int MODE> constexpr int bwd_waves() { return MODE == 0 ? 8 : 4; }
-template <int D, int MODE> constexpr int bwd_lds_bytes() { return 2 * kBwdStages * kBN * D * 2 + (MODE == 1 ? kBwdStages * 1024 : 0); }
+template <int MODE> constexpr int bwd_stages() { return MODE == 0 ? 3 : 4; }       // LDS ring depth (tiles)
+template <int D, int MODE> constexpr int bwd_lds_bytes() { return 2 * bwd_stages<MODE>() * kBN * D * 2 + (MODE == 1 ? bwd_stages<MODE>() * 1024 : 0); }
 
 // 16-byte-chunk swizzle of a streamed tile: serves the 16x16x32 row reads (16 lanes = 16 rows at one chunk)
 // and the transposed reads (a 32-lane half = 8 consecutive rows x 32 bytes) without bank conflicts.
@@ -125,7 +127,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     constexpr int TILE = kBN * ROWB;           // bytes per streamed tile
     constexpr int PIECE = 1024;                // bytes one DMA wave-instruction moves
     constexpr int CPT = TILE / PIECE / NW;     // DMA pieces per wave per tile
-    constexpr int NS = kBwdStages;
+    constexpr bool PIPE = MODE == 1;           // one wave per SIMD: software-pipelined block loop
+    constexpr int NS = bwd_stages<MODE>();
+    constexpr int NBUF = PIPE ? 2 : 1;
     constexpr int Y2BASE = NS * TILE;
     constexpr int STBASE = 2 * NS * TILE;      // MODE 1: NS x 1 KiB of row statistics
     static_assert(CPT >= 1, "tile too small for the workgroup");
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
     const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
     const unsigned piece_base = lds_base + wave * CPT * PIECE;          // wave-uniform
-    // statistics of a 64-row tile (MODE 1, wave 0): lanes 0-15 fetch LSE*log2e, lanes 16-31 delta, 16 bytes each
+    // statistics of a 64-row tile (MODE 1): lanes 0-15 fetch LSE*log2e, lanes 16-31 delta, 16 bytes each
     const u32x4 rst = make_rsrc(p.stats, (unsigned)((long long)2 * p.bh * p.Spad * 4));
     unsigned g_st = 0x80000000u;
     if constexpr (MODE == 1) {
@@ -237,9 +241,11 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     }
     auto issue_tile = [&](int j, int stage) {
         if constexpr (MODE == 1) {
-            // past the last tile the offset leaves the descriptor only for the delta plane's tail; the LSE lanes
-            // may then read the next head's rows -- harmless, such tiles are never computed on
-            if (wave == 0) dma16(rst, __builtin_amdgcn_readfirstlane(lds_base + STBASE + stage * 1024), g_st + (unsigned)j * (kBN * 4));
+            // every wave fetches the same 1 KiB (identical bytes to one place): no branch in the tile loop, so a
+            // whole unrolled trip stays one basic block for the scheduler.  Past the last tile the offset leaves the
+            // descriptor only for the delta plane's tail; the LSE lanes may then read the next head's rows --
+            // harmless, such tiles are never computed on.
+            dma16(rst, __builtin_amdgcn_readfirstlane(lds_base + STBASE + stage * 1024), g_st + (unsigned)j * (kBN * 4));
         }
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
@@ -250,15 +256,28 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     };
 
     // ---- LDS read addresses (stage 0, block 0)
-    unsigned ra[KS];           // row reads: lane (li, lg) reads row li (+16 yt + 32 blk), chunk 4 ks + lg
+    // (ring stage, block and tile offsets are added as instruction immediates: < 64 KiB per ring)
+    unsigned ra[KS], ra2[KS];  // row reads: lane (li, lg) reads row li (+16 yt + 32 blk), chunk 4 ks + lg
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ra[ks] = lds_base + li * ROWB + bwd_swz<D>(li, 4 * ks + lg) * 16;
-    unsigned ta[DT];           // transposed reads: lane 4 qq + pp of a 16-lane group supplies row 4 lg + qq, columns 16 dt + 4 pp .. +3
+    for (int ks = 0; ks < KS; ++ks) {
+        ra[ks] = lds_base + li * ROWB + bwd_swz<D>(li, 4 * ks + lg) * 16;
+        ra2[ks] = ra[ks] + Y2BASE;
+        asm volatile("" : "+v"(ra2[ks]));                   // opaque: keeps it a register of its own (the sum would not fit an immediate)
+    }
+    unsigned sta = lds_base + STBASE + lg * 16;            // statistics of rows 4 lg .. +3 (+16 yt + 32 blk)
+    asm volatile("" : "+v"(sta));
+    unsigned ta[DT], ta2[MODE == 1 ? DT : 1];   // transposed reads: lane 4 qq + pp of a 16-lane group supplies row 4 lg + qq, columns 16 dt + 4 pp .. +3
     {
         const int qq = li >> 2, pp = li & 3;
         const int row = 4 * lg + qq;                  // + 16 a + 32 blk: multiples of 16 rows, swizzle-neutral
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) ta[dt] = lds_base + row * ROWB + bwd_swz<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+        for (int dt = 0; dt < DT; ++dt) {
+            ta[dt] = lds_base + row * ROWB + bwd_swz<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+            if constexpr (MODE == 1) {
+                ta2[dt] = ta[dt] + Y2BASE;
+                asm volatile("" : "+v"(ta2[dt]));
+            }
+        }
     }
 
     f32x4 acc1[DT][2];         // MODE 0: dQ^T ; MODE 1: dK^T   [head_dim tile][x tile]
@@ -272,36 +291,56 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
         }
     const float c = p.scale_log2;
 
-    // ---- one 32-row block of the tile in ring stage `stage`
-    auto compute_block = [&] __device__ (auto mask_c, int stage, int blk, int y0) {
-        constexpr bool MASK = decltype(mask_c)::value;
+    // ---- a 32-row block passes through three steps; PAR selects one of two register sets (software pipeline)
+    f32x4 t1[NBUF][2][2], t2[NBUF][2][2];          // score accumulators [set][y tile][x tile]
+    u32x4 pw[NBUF][2], dsw[NBUF][2];               // packed P and dS: B operands, element 4 yt + e <-> y = 16 yt + 4 lg + e
+
+    // SC: T1 = Y1 . X1^T, T2 = Y2 . X2^T for block `blk` of the tile in ring stage `stage`
+    // (`stage` and `blk` are ints or integral constants: constants turn every LDS offset into an immediate)
+    auto step_scores = [&] __device__ (auto par_c, auto stage, auto blk) {
+        constexpr int PAR = decltype(par_c)::value;
         const unsigned so = stage * TILE + blk * 32 * ROWB;
-        f32x4 t1[2][2], t2[2][2];                     // [y tile][x tile]
 #pragma unroll
         for (int yt = 0; yt < 2; ++yt) {
-            t1[yt][0] = t1[yt][1] = t2[yt][0] = t2[yt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!PIPE) t1[PAR][yt][0] = t1[PAR][yt][1] = t2[PAR][yt][0] = t2[PAR][yt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const u32x4 a1 = lds_read_b128(ra[ks] + so + yt * 16 * ROWB);
-                const u32x4 a2 = lds_read_b128(ra[ks] + Y2BASE + so + yt * 16 * ROWB);
+                const u32x4 a1 = lds_read_b128(ra[ks] + (so + yt * 16 * ROWB));
+                const u32x4 a2 = lds_read_b128(ra2[ks] + (so + yt * 16 * ROWB));
 #pragma unroll
                 for (int xt = 0; xt < 2; ++xt) {
-                    t1[yt][xt] = T::mfma16(a1, xf1[xt][ks], t1[yt][xt]);
-                    t2[yt][xt] = T::mfma16(a2, xf2[xt][ks], t2[yt][xt]);
+                    if constexpr (PIPE) {
+                        // 512-register kernel: scores go to arch VGPRs (see mfma16_v_first); the callers keep VALU
+                        // readers of t1/t2 away from these MFMAs
+                        if (ks == 0) {
+                            T::mfma16_v_first(t1[PAR][yt][xt], a1, xf1[xt][ks]);
+                            T::mfma16_v_first(t2[PAR][yt][xt], a2, xf2[xt][ks]);
+                        } else {
+                            T::mfma16_v_acc(t1[PAR][yt][xt], a1, xf1[xt][ks]);
+                            T::mfma16_v_acc(t2[PAR][yt][xt], a2, xf2[xt][ks]);
+                        }
+                    } else {
+                        t1[PAR][yt][xt] = T::mfma16(a1, xf1[xt][ks], t1[PAR][yt][xt]);
+                        t2[PAR][yt][xt] = T::mfma16(a2, xf2[xt][ks], t2[PAR][yt][xt]);
+                    }
                 }
             }
         }
+    };
+    // EW: P = exp2(T1 c - LSE2) (masked), dS = P (T2 - delta), packed to 16 bits
+    auto step_softmax = [&] __device__ (auto mask_c, auto par_c, auto stage, auto blk, int y0) {
+        constexpr bool MASK = decltype(mask_c)::value;
+        constexpr int PAR = decltype(par_c)::value;
         // row statistics of the streamed rows (MODE 1): rows 16 yt + 4 lg + 0..3 of the block
         f32x4 lse_y[2], delta_y[2];
         if constexpr (MODE == 1) {
 #pragma unroll
             for (int yt = 0; yt < 2; ++yt) {
-                const unsigned sa = lds_base + STBASE + stage * 1024 + (blk * 32 + 16 * yt + 4 * lg) * 4;
-                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sa));
-                delta_y[yt] = bitcast<f32x4>(lds_read_b128(sa + 256));
+                const unsigned so = stage * 1024 + (blk * 32 + 16 * yt) * 4;
+                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + so));
+                delta_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (so + 256)));
             }
         }
-        u32x4 pw[2], dsw[2];                           // packed P and dS: B operands, element 4 yt + e <-> y = 16 yt + 4 lg + e
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
             const int xrow = x0w + 16 * xt + li;
@@ -312,60 +351,153 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
                 for (int e = 0; e < 4; ++e) {
                     const float l2 = (MODE == 0) ? lse_x[xt] : lse_y[yt][e];
                     const float dl = (MODE == 0) ? delta_x[xt] : delta_y[yt][e];
-                    float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[yt][xt][e], c, -l2));
+                    float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[PAR][yt][xt][e], c, -l2));
                     if constexpr (MASK) {
                         const int yrow = y0 + 16 * yt + 4 * lg + e;
                         const bool dead = (MODE == 0) ? (yrow > xrow) : (xrow > yrow);     // key > query
                         if (dead) pe = 0.f;
                     }
                     pv[e] = pe;
-                    dv[e] = pe * (t2[yt][xt][e] - dl);
+                    dv[e] = pe * (t2[PAR][yt][xt][e] - dl);
                 }
                 if constexpr (MODE == 1) {
-                    pw[xt][2 * yt] = T::pack2(pv[0], pv[1]);
-                    pw[xt][2 * yt + 1] = T::pack2(pv[2], pv[3]);
+                    pw[PAR][xt][2 * yt] = T::pack2(pv[0], pv[1]);
+                    pw[PAR][xt][2 * yt + 1] = T::pack2(pv[2], pv[3]);
                 }
-                dsw[xt][2 * yt] = T::pack2(dv[0], dv[1]);
-                dsw[xt][2 * yt + 1] = T::pack2(dv[2], dv[3]);
-            }
-        }
-        // gradient products: A = Y^T fragments through the transposed read (rows 4 lg .. +3 and 16 + 4 lg .. +3 of the block)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const u32x2 lo1 = lds_read_tr16_b64(ta[dt] + so);
-            const u32x2 hi1 = lds_read_tr16_b64(ta[dt] + so + 16 * ROWB);
-            const u32x4 a1 = {lo1[0], lo1[1], hi1[0], hi1[1]};
-#pragma unroll
-            for (int xt = 0; xt < 2; ++xt) acc1[dt][xt] = T::mfma16(a1, dsw[xt], acc1[dt][xt]);
-            if constexpr (MODE == 1) {
-                const u32x2 lo2 = lds_read_tr16_b64(ta[dt] + Y2BASE + so);
-                const u32x2 hi2 = lds_read_tr16_b64(ta[dt] + Y2BASE + so + 16 * ROWB);
-                const u32x4 a2 = {lo2[0], lo2[1], hi2[0], hi2[1]};
-#pragma unroll
-                for (int xt = 0; xt < 2; ++xt) acc2[dt][xt] = T::mfma16(a2, pw[xt], acc2[dt][xt]);
+                dsw[PAR][xt][2 * yt] = T::pack2(dv[0], dv[1]);
+                dsw[PAR][xt][2 * yt + 1] = T::pack2(dv[2], dv[3]);
             }
         }
     };
+    // GR: gradient products, A = Y^T fragments through the transposed read (rows 4 lg .. +3 and 16 + 4 lg .. +3 of the block)
+    auto grad_frag = [&] __device__ (unsigned (&base)[DT], int dt, unsigned so) {
+        const u32x2 lo = lds_read_tr16_b64(base[dt] + so);
+        const u32x2 hi = lds_read_tr16_b64(base[dt] + (so + 16 * ROWB));
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    auto step_grads = [&] __device__ (auto par_c, auto stage, auto blk, auto dt_lo, auto dt_hi) {
+        constexpr int PAR = decltype(par_c)::value;
+        const unsigned so = stage * TILE + blk * 32 * ROWB;
+#pragma unroll
+        for (int dt = decltype(dt_lo)::value; dt < decltype(dt_hi)::value; ++dt) {
+            const u32x4 a1 = grad_frag(ta, dt, so);
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt) acc1[dt][xt] = T::mfma16(a1, dsw[PAR][xt], acc1[dt][xt]);
+            if constexpr (MODE == 1) {
+                const u32x4 a2 = grad_frag(ta2, dt, so);
+#pragma unroll
+                for (int xt = 0; xt < 2; ++xt) acc2[dt][xt] = T::mfma16(a2, pw[PAR][xt], acc2[dt][xt]);
+            }
+        }
+    };
+    auto needs_mask = [&](int bi) { return CAUSAL && bi >= blk_mask_lo && bi <= blk_mask_hi; };
 
     // ---- main loop: tile j lives in ring stage (j - j_begin) % NS; tile j + 2 is issued behind barrier j
-    constexpr int OPS = 2 * CPT;                      // DMA instructions per tile and wave (wave 0 of MODE 1: one more, issued first)
+    constexpr int OPS = 2 * CPT + (MODE == 1 ? 1 : 0);   // DMA instructions per tile and wave
     if (j_begin < j_end) {
         issue_tile(j_begin, 0);
         issue_tile(j_begin + 1, 1);
         int stage = 0;
-        for (int j = j_begin; j < j_end; ++j) {
-            dma_wait<OPS>();                          // this wave's pieces of tile j have landed ...
-            __syncthreads();                          // ... every wave's are visible, and tile j-1 is no longer read
-            issue_tile(j + 2, stage == 0 ? 2 : stage - 1);
+        if constexpr (!PIPE) {
+            // two waves per SIMD: the hardware interleaves one wave's matrix steps with its partner's softmax
+            for (int j = j_begin; j < j_end; ++j) {
+                dma_wait<OPS>();                      // this wave's pieces of tile j have landed ...
+                __syncthreads();                      // ... every wave's are visible, and tile j-1 is no longer read
+                issue_tile(j + 2, (stage + 2) % NS);
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const int bi = 2 * j + blk;
-                if (bi >= blk_begin_w && bi < blk_end_w) {
-                    if (CAUSAL && bi >= blk_mask_lo && bi <= blk_mask_hi) compute_block(std::true_type{}, stage, blk, bi * 32);
-                    else compute_block(std::false_type{}, stage, blk, bi * 32);
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int bi = 2 * j + blk;
+                    if (bi >= blk_begin_w && bi < blk_end_w) {
+                        step_scores(IC<0>{}, stage, blk);
+                        if (needs_mask(bi)) step_softmax(std::true_type{}, IC<0>{}, stage, blk, bi * 32);
+                        else step_softmax(std::false_type{}, IC<0>{}, stage, blk, bi * 32);
+                        step_grads(IC<0>{}, stage, blk, IC<0>{}, IC<DT>{});
+                    }
                 }
+                stage = (stage == NS - 1) ? 0 : stage + 1;
             }
-            stage = (stage == NS - 1) ? 0 : stage + 1;
+        } else {
+            // one wave per SIMD: software pipeline over blocks -- iteration i runs the matrix products of scores(i)
+            // and grads(i-2) around the softmax of block i-1, all three independent of each other.  Block i reads
+            // tile i/2 (rows), block i-2 tile i/2 - 1 (transposed): barrier j therefore retires tile j-2, whose ring
+            // stage (of 4) receives tile j+2.  One extra trip drains the pipeline.
+            auto iteration = [&] __device__ (auto par_c, int i, auto st, auto sp) {
+                constexpr int PAR = decltype(par_c)::value;              // = i & 1 = block of the tile
+                const bool do_sc = i >= blk_begin_w && i < blk_end_w;
+                const bool do_ew = i - 1 >= blk_begin_w && i - 1 < blk_end_w;
+                const bool do_gr = i - 2 >= blk_begin_w && i - 2 < blk_end_w;
+                // scores(i): tile i/2 = stage st; softmax(i-1): tile (i-1)/2 = st (odd i) or sp (even i); grads(i-2): sp
+                if (do_gr) step_grads(IC<PAR>{}, sp, IC<PAR>{}, IC<0>{}, IC<DT>{});
+                if (do_ew) {
+                    if constexpr (PAR == 1) {
+                        if (needs_mask(i - 1)) step_softmax(std::true_type{}, IC<0>{}, st, IC<0>{}, (i - 1) * 32);
+                        else step_softmax(std::false_type{}, IC<0>{}, st, IC<0>{}, (i - 1) * 32);
+                    } else {
+                        if (needs_mask(i - 1)) step_softmax(std::true_type{}, IC<1>{}, sp, IC<1>{}, (i - 1) * 32);
+                        else step_softmax(std::false_type{}, IC<1>{}, sp, IC<1>{}, (i - 1) * 32);
+                    }
+                }
+                if (do_sc) {
+                    step_scores(IC<PAR>{}, st, IC<PAR>{});
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // MFMA -> VALU wait states of the asm score MFMAs
+                }
+            };
+            // steady state (all three steps live, no mask): one straight-line region per block, ring stage known
+            // at compile time, the scheduler interleaves the three independent steps
+            auto fused = [&] __device__ (auto par_c, auto st_c) {
+                constexpr int PAR = decltype(par_c)::value, ST = decltype(st_c)::value;
+                typedef IC<ST> SC_ST;
+                typedef IC<(ST + NS - 1) % NS> GR_ST;
+                typedef IC<(PAR == 1 ? ST : (ST + NS - 1) % NS)> EW_ST;
+                __builtin_amdgcn_sched_barrier(0);
+                step_scores(IC<PAR>{}, SC_ST{}, IC<PAR>{});
+                step_softmax(std::false_type{}, IC<PAR ^ 1>{}, EW_ST{}, IC<PAR ^ 1>{}, 0);
+                step_grads(IC<PAR>{}, GR_ST{}, IC<PAR>{}, IC<0>{}, IC<DT - 1>{});
+                // the region ends with four compiler-visible MFMAs (64 cycles): the next region's softmax reads the
+                // asm score MFMAs' results no earlier than that (their MFMA -> VALU wait states)
+                const unsigned so = GR_ST::value * TILE + PAR * 32 * ROWB;
+                const u32x4 l1 = grad_frag(ta, DT - 1, so);
+                const u32x4 l2 = grad_frag(ta2, DT - 1, so);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int xt = 0; xt < 2; ++xt) {
+                    acc1[DT - 1][xt] = T::mfma16(l1, dsw[PAR][xt], acc1[DT - 1][xt]);
+                    acc2[DT - 1][xt] = T::mfma16(l2, pw[PAR][xt], acc2[DT - 1][xt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto sync_and_issue = [&](int j, int dst_stage) {
+                dma_wait<OPS>();
+                __syncthreads();
+                issue_tile(j + 2, dst_stage);
+            };
+            int j = j_begin;
+            while (j <= j_end) {
+                // four tiles whose eight blocks are all in the steady state, starting at ring stage 0
+                if (stage == 0 && j + 3 < j_end && 2 * j - 2 >= blk_begin_w && 2 * j + 7 < blk_end_w &&
+                    !(CAUSAL && 2 * j - 1 <= blk_mask_hi && 2 * j + 6 >= blk_mask_lo)) {
+                    sync_and_issue(j, 2);
+                    fused(IC<0>{}, IC<0>{});
+                    fused(IC<1>{}, IC<0>{});
+                    sync_and_issue(j + 1, 3);
+                    fused(IC<0>{}, IC<1>{});
+                    fused(IC<1>{}, IC<1>{});
+                    sync_and_issue(j + 2, 0);
+                    fused(IC<0>{}, IC<2>{});
+                    fused(IC<1>{}, IC<2>{});
+                    sync_and_issue(j + 3, 1);
+                    fused(IC<0>{}, IC<3>{});
+                    fused(IC<1>{}, IC<3>{});
+                    j += 4;
+                    continue;
+                }
+                if (j < j_end) sync_and_issue(j, (stage + 2) % NS);
+                const int sp = (stage + NS - 1) % NS;
+                iteration(IC<0>{}, 2 * j, stage, sp);
+                iteration(IC<1>{}, 2 * j + 1, stage, sp);
+                stage = (stage + 1) % NS;
+                ++j;
+            }
         }
         dma_wait<0>();                                // no DMA may still be writing LDS when the workgroup retires
     }

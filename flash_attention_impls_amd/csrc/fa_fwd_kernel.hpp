@@ -86,6 +86,16 @@ struct TypeBF16 {
         f32x2 f = {a, b};
         return bitcast<unsigned>(__builtin_convertvector(f, bf16x2));
     }
+    // 16x16x32 MFMA with an arch-VGPR destination and the B operand in the accumulator file, through inline asm:
+    // in a 512-register kernel hipcc gives every builtin MFMA an AGPR destination, which costs one v_accvgpr_read
+    // per element that VALU code consumes.  The caller keeps the result away from non-MFMA readers for the
+    // MFMA -> VALU wait states (nothing inside or after the string is padded by the compiler).
+    static __device__ __forceinline__ void mfma16_v_first(f32x4& d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void mfma16_v_acc(f32x4& d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
 };
 struct TypeF16 {
     static constexpr float kPBias = 6.0f;
@@ -99,6 +109,12 @@ struct TypeF16 {
     static __device__ __forceinline__ unsigned pack2(float a, float b) {
         f32x2 f = {a, b};
         return bitcast<unsigned>(__builtin_convertvector(f, f16x2));
+    }
+    static __device__ __forceinline__ void mfma16_v_first(f32x4& d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void mfma16_v_acc(f32x4& d, u32x4 a, u32x4 b) {
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
     }
 };
 
