@@ -154,7 +154,9 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     pk.o2_sb = st[7][0]; pk.o2_sh = st[7][1]; pk.o2_ss = st[7][2];
     pk.nxb = (S + 32 * fa::bwd_waves<1>() - 1) / (32 * fa::bwd_waves<1>());
 
-    const int grid_q = bwd_grid((long long)B * H, pq.nxb), grid_k = bwd_grid((long long)B * H, pk.nxb);
+    // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp)
+    const int grid_q = bwd_grid((long long)B * H, causal != 0 ? (pq.nxb + 1) / 2 : pq.nxb);
+    const int grid_k = bwd_grid((long long)B * H, pk.nxb);
     if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     const bool c = causal != 0;
     if (dtype == FA_DTYPE_BF16)

@@ -140,24 +140,34 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
-    const int li = lane & 15;
-    const int lg = lane >> 4;
 
     // workgroup -> (head, stationary block); blockIdx % 8 = XCD: all blocks of a head share one L2
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int hl = slot / p.nxb;
-    const int t = slot - hl * p.nxb;
+    // MODE 0 under the causal mask: a workgroup takes the query-block pair (nxb-1-t, t), so that every workgroup
+    // streams nxb+1 blocks' worth of tiles (a balanced grid, as in the forward); MODE 1 launches the heaviest key
+    // blocks (the first ones) first
+    constexpr bool PAIR = MODE == 0 && CAUSAL;
+    const int wg_per_head = PAIR ? (p.nxb + 1) / 2 : p.nxb;
+    const int hl = slot / wg_per_head;
+    const int t = slot - hl * wg_per_head;
     const int head = hl * 8 + xcd;
     if (head >= p.bh) return;
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;
-    // heaviest first under the causal mask: the last query block (MODE 0) / the first key block (MODE 1)
-    const int xb = (MODE == 0 && CAUSAL) ? p.nxb - 1 - t : t;
+    const int n_pass = (PAIR && p.nxb - 1 - t != t) ? 2 : 1;
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int xb = PAIR ? (pass == 0 ? p.nxb - 1 - t : t) : t;
     const int x0 = xb * XB;                    // first stationary row of the workgroup
-    const int x0w = x0 + wave * 32;            // ... of this wave
+    asm volatile("" : "+v"(lane));             // per-pass opaque lane id: nothing derived from it is hoisted out of the pass loop
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    // MODE 0 under the causal mask: waves w and w+4 share a SIMD; row blocks that sum to 7 give every SIMD the same
+    // number of blocks on the workgroup's diagonal tiles
+    const int rowblk_of_wave = (MODE == 0 && CAUSAL && wave >= 4) ? 11 - wave : wave;
+    const int x0w = x0 + rowblk_of_wave * 32;  // ... of this wave
 
     using elem_t = unsigned short;
     const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh;
@@ -526,6 +536,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     };
     store_out(acc1, p.out1, p.o1_sb, p.o1_sh, p.o1_ss, p.scale);
     if constexpr (MODE == 1) store_out(acc2, p.out2, p.o2_sb, p.o2_sh, p.o2_ss, 1.0f);
+    if (pass + 1 < n_pass) __syncthreads();           // every wave is done with the ring before the next pass refills it
+  }  // pass
 }
 
 }  // namespace fa
