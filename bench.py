@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"],
+                    help="fwd: the headline metric (forward only).  fwdbwd: forward + backward through the autograd "
+                         "Function with a fixed upstream gradient (the attention part of the reference's fwd_bwd step, "
+                         "FA2-triton.py:357-365), 3.5 x the forward FLOPs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
@@ -153,7 +157,29 @@ def main():
         if not parity <= tol * max(1.0, float(ref.abs().max())):
             sys.exit(f"parity gate failed: max|o-ref|={parity}")
 
+    fwdbwd = args.mode == "fwdbwd"
+    if fwdbwd:
+        if w["dtype"] == "fp8":
+            sys.exit("--mode fwdbwd: fp8 inputs are forward-only")
+        q, k, v = (t.requires_grad_(True) for t in (q, k, v))
+        d_out = torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(dt)
+        if rank == 0:           # parity gate of the backward (small shape, oracle as the checker)
+            g = torch.Generator().manual_seed(2)
+            qs, ks, vs, gs = (torch.randn(1, 2, 333, D, generator=g).to(dt) for _ in range(4))
+            leaves = [t.to(dev).requires_grad_(True) for t in (qs, ks, vs)]
+            fa.flash_attn(*leaves, causal).backward(gs.to(dev))
+            refs = orc.sdpa_bwd_oracle(qs, ks, vs, gs, causal)[1:]
+            for leaf, ref_g in zip(leaves, refs):
+                e = float((leaf.grad.float().cpu() - ref_g).abs().max())
+                if not e <= (2e-3 if w["dtype"] == "fp16" else 1.6e-2) * max(1.0, float(ref_g.abs().max())):
+                    sys.exit(f"backward parity gate failed: max|g-ref|={e}")
+
     def step():
+        if fwdbwd:
+            q.grad = k.grad = v.grad = None
+            o = fa.flash_attn(q, k, v, causal)
+            o.backward(d_out)
+            return o
         return fa.flash_attn(q, k, v, causal, descale=descale)
 
     def barrier():
@@ -185,8 +211,10 @@ def main():
     kt = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
     kernel_ms = sum(kt) / len(kt)
 
-    flops_rank = attn_flops(B, H, S, D, causal)
+    flops_rank = attn_flops(B, H, S, D, causal) * (3.5 if fwdbwd else 1.0)
     bytes_rank = attn_bytes(B, H, S, D, in_bytes=1 if w["dtype"] == "fp8" else 2)
+    if fwdbwd:      # backward: q, k, v, o, dO and the LSE read once, dq, dk, dv written once
+        bytes_rank += 8.0 * B * H * S * D * 2 + B * H * S * 4
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops_rank / (elapsed / args.steps) / 1e12
     compute_dtype = "bf16" if w["dtype"] == "fp8" else w["dtype"]     # fp8 inputs are computed with bf16 MFMAs
@@ -195,7 +223,7 @@ def main():
 
     gather = None
     if dist is not None and not args.no_gather and not rehearsal:
-        o = step()
+        o = step().detach()
         full = torch.empty((world * B, H, S, D), dtype=o.dtype, device=dev)
         for _ in range(2):
             dist.all_gather_into_tensor(full, o)
@@ -213,7 +241,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "attn_fwd_tflops", "value": value, "unit": "TFLOP/s",
+            "metric": "attn_fwdbwd_tflops" if fwdbwd else "attn_fwd_tflops", "value": value, "unit": "TFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": compute_dtype, "input_dtype": w["dtype"], "data": "synthetic",
@@ -221,12 +249,14 @@ def main():
                                    f"{'causal' if causal else 'non-causal'} per GPU (BASELINE.json metric config)",
                        "B_per_gpu": B, "H": H, "S": S, "D": D, "causal": causal,
                        "sharding": f"batch x head units split over {world} rank(s), no data-path collective",
-                       "flops_rule": "4*B*H*S^2*D, halved when causal (FA2 convention)"},
+                       "flops_rule": "4*B*H*S^2*D, halved when causal (FA2 convention)" +
+                                     (" x 3.5 (forward + five backward products / two)" if fwdbwd else ""),
+                       "mode": args.mode},
             "pct_mfma_peak": 100.0 * value / (world * peak),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "traffic": (measured_traffic(args.workload) or {}).get("bytes_per_launch"),
-                         "traffic_source": (measured_traffic(args.workload) or {}).get("source"),
+                         "traffic": (measured_traffic(args.workload + ("_fwdbwd" if fwdbwd else "")) or {}).get("bytes_per_launch"),
+                         "traffic_source": (measured_traffic(args.workload + ("_fwdbwd" if fwdbwd else "")) or {}).get("source"),
                          "kernel_ms_avg": kernel_ms, "kernel_ms_min": kt[0],
                          "algorithmic_flops_per_launch": flops_rank,
                          "algorithmic_bytes_per_launch": bytes_rank,

@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 --pmc csv outputs: per counter, the mean over dispatches of fa_fwd kernels."""
+"""Summarise rocprofv3 --pmc csv outputs: per kernel (fa_* only) and counter, the mean over dispatches."""
 import csv
 import glob
 import os
@@ -10,14 +10,16 @@ acc = defaultdict(list)
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "fa_fwd" not in row.get("Kernel_Name", ""):
+            name = row.get("Kernel_Name", "")
+            if "fa::fa_" not in name:
                 continue
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+            short = name[name.index("fa::") + 4:name.rindex("(")].replace("fa::", "")
+            acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
 lines = []
 for k in sorted(acc):
     v = acc[k]
     # each dispatch may be reported per-dimension rows; report mean of rows and count
-    lines.append(f"{k:36s} mean={sum(v)/len(v):.6g} n={len(v)} min={min(v):.6g} max={max(v):.6g}")
+    lines.append(f"{k[0]:58s} {k[1]:34s} mean={sum(v)/len(v):.6g} n={len(v)} min={min(v):.6g} max={max(v):.6g}")
 txt = "\n".join(lines)
 print(txt)
 open(os.path.join(out, "summary.txt"), "w").write(txt + "\n")

@@ -16,11 +16,18 @@ ap.add_argument("--D", type=int, default=128)
 ap.add_argument("--causal", type=int, default=1)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--bwd", type=int, default=0, help="1: time forward + backward steps (autograd path)")
 a = ap.parse_args()
 dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
 torch.manual_seed(0)
 q, k, v = (torch.randn(a.B, a.H, a.S, a.D, device="cuda").to(dt) for _ in range(3))
+if a.bwd:
+    q, k, v = (t.requires_grad_(True) for t in (q, k, v))
+    do = torch.randn_like(q)
 for _ in range(a.iters):
     o = flash_attn(q, k, v, bool(a.causal))
+    if a.bwd:
+        o.backward(do)
+        q.grad = k.grad = v.grad = None
 torch.cuda.synchronize()
 print("done", float(o.float().abs().mean()))
