@@ -53,5 +53,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+CLI_SRC = os.path.join(PKG_DIR, "cli", "fa_bench.cpp")
+CLI_PATH = os.path.join(PKG_DIR, "cli", "fa_bench")
+
+
+def build_cli(verbose: bool = False) -> str:
+    """Compile the native bench/verify CLI (host-only C++ over the C ABI) next to its source."""
+    build()
+    cmd = [hipcc_path(), "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", CLI_SRC, "-o", CLI_PATH,
+           "-L" + PKG_DIR, "-lfa_mi355", "-Wl,-rpath,$ORIGIN/.."]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc (cli) failed:\n" + res.stdout + res.stderr)
+    return CLI_PATH
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_cli(verbose=True))

@@ -36,3 +36,50 @@ def attn_bytes(B: int, H: int, S: int, D: int, in_bytes: int = 2, out_bytes: int
     """Q+K+V read once, O written once (test_flash_attn.cu:316-320), plus the fp32 LSE."""
     n = B * H * S * D
     return 3.0 * n * in_bytes + n * out_bytes + B * H * S * 4
+
+
+def try_max_batch(flash_attention, base_B: int = 1, H: int = 16, N: int = 1024, D: int = 32,
+                  dtype=torch.float16, causal: bool = True, limit_B: int | None = None):
+    """Largest batch whose forward + backward step fits in device memory, as the reference probes it
+    (``try_max_batch``, FA2-triton.py:270-309): double the batch until an out-of-memory error, then binary
+    search; one step = flash_attention(q,k,v) -> loss = o.float().pow(2).mean() -> backward.
+    ``limit_B`` (not in the reference) bounds the search so that a shared box is not driven out of memory:
+    the probe never allocates a batch above it and returns it when everything up to it fits."""
+    device = "cuda"
+
+    def fits(bsz: int) -> bool:
+        try:
+            q = torch.randn(bsz, H, N, D, device=device, dtype=dtype, requires_grad=True)
+            k = torch.randn_like(q, requires_grad=True)
+            v = torch.randn_like(q, requires_grad=True)
+            o = flash_attention(q, k, v, causal=causal)
+            loss = o.float().pow(2).mean()
+            loss.backward()
+            del q, k, v, o, loss
+            torch.cuda.empty_cache()
+            return True
+        except RuntimeError as e:
+            if "out of memory" in str(e).lower():
+                torch.cuda.empty_cache()
+                return False
+            raise
+
+    low, high = 1, base_B
+    while True:                                   # grow until OOM (:274-289)
+        if limit_B is not None and high > limit_B:
+            high = limit_B + 1
+            break
+        if fits(high):
+            low = high
+            high *= 2
+        else:
+            break
+    L, R, best = low, high - 1, low               # binary search in (low, high) (:290-308)
+    while L <= R:
+        mid = (L + R) // 2
+        if fits(mid):
+            best = mid
+            L = mid + 1
+        else:
+            R = mid - 1
+    return best

@@ -1,0 +1,123 @@
+// fa_bench -- Python-free bench / verify CLI over the C ABI (include/fa_mi355.h), in the spirit of the
+// reference's native harnesses:
+//   code/cuda_fa1/main.cu:365-483                        argv "B H N d M runs", verify, then time, then ms / GB/s / GFLOP/s
+//   code/cutlass_cuda_fa1/run/test_flash_attn.cu:184-347 PASS rule max|a-b|/(|a|+|b|+1e-5) < 0.02 (:108-143, :297-299),
+//                                                        FLOPs 4*B*H*N^2*d (:308), bytes Q+K+V+O (:316-320)
+// usage: fa_bench [B H N d [runs [causal [bf16|fp16]]]]      defaults 1 8 512 64 50 0 fp16 (main.cu's defaults)
+// Links nothing but the HIP runtime and libfa_mi355.so: what a C/C++ consumer of the library would write.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../include/fa_mi355.h"
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+
+static uint16_t f32_to_bf16(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f32_to_f16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float f16_to_f32(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+int main(int argc, char** argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 1;
+    const int H = argc > 2 ? atoi(argv[2]) : 8;
+    const int N = argc > 3 ? atoi(argv[3]) : 512;
+    const int d = argc > 4 ? atoi(argv[4]) : 64;
+    const int runs = argc > 5 ? atoi(argv[5]) : 50;
+    const int causal = argc > 6 ? atoi(argv[6]) : 0;
+    const bool bf16 = argc > 7 && strcmp(argv[7], "bf16") == 0;
+    const int dtype = bf16 ? FA_DTYPE_BF16 : FA_DTYPE_FP16;
+    printf("Flash Attention Performance Test (MI355X, libfa_mi355 %d)\n", fa_version());
+    printf("B=%d, H=%d, N=%d, d=%d, runs=%d, causal=%d, dtype=%s\n", B, H, N, d, runs, causal, bf16 ? "bf16" : "fp16");
+    if (!fa_supported(dtype, d)) { fprintf(stderr, "head_dim %d has no compiled kernel (64, 128)\n", d); return 1; }
+
+    const size_t n = (size_t)B * H * N * d;
+    std::vector<uint16_t> hq(n), hk(n), hv(n), ho(n);
+    std::mt19937 rng(0);
+    std::uniform_real_distribution<float> uni(-1.f, 1.f);           // init_random_half of main.cu: uniform values
+    auto fill = [&](std::vector<uint16_t>& t) { for (auto& x : t) { float f = uni(rng); x = bf16 ? f32_to_bf16(f) : f32_to_f16(f); } };
+    fill(hq); fill(hk); fill(hv);
+    auto to_f32 = [&](uint16_t x) { return bf16 ? bf16_to_f32(x) : f16_to_f32(x); };
+
+    void *Q, *K, *V, *O;
+    float* lse;
+    HIP_OK(hipMalloc(&Q, n * 2)); HIP_OK(hipMalloc(&K, n * 2)); HIP_OK(hipMalloc(&V, n * 2)); HIP_OK(hipMalloc(&O, n * 2));
+    HIP_OK(hipMalloc((void**)&lse, (size_t)B * H * N * 4));
+    HIP_OK(hipMemcpy(Q, hq.data(), n * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(K, hk.data(), n * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(V, hv.data(), n * 2, hipMemcpyHostToDevice));
+
+    auto launch = [&]() { return fa_fwd(Q, K, V, O, lse, B, H, N, d, nullptr, nullptr, nullptr, nullptr, dtype, causal, 0.f, nullptr, nullptr); };
+    if (int rc = launch()) { fprintf(stderr, "fa_fwd failed (%d): %s\n", rc, fa_last_error()); return 1; }
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(ho.data(), O, n * 2, hipMemcpyDeviceToHost));
+
+    // verification: naive fp32 attention on the host for the first and the last (batch, head), a bounded row sample
+    const float scale = 1.0f / std::sqrt((float)d);
+    std::vector<float> refs, gots;
+    const int step = N > 256 ? N / 256 : 1;
+    std::vector<float> sc(N);
+    for (int which = 0; which < 2; ++which) {
+        const size_t bh = which == 0 ? 0 : (size_t)B * H - 1;
+        const uint16_t *q = &hq[bh * N * d], *k = &hk[bh * N * d], *v = &hv[bh * N * d], *o = &ho[bh * N * d];
+        for (int i = 0; i < N; i += step) {
+            const int lim = causal ? i + 1 : N;
+            float mx = -INFINITY;
+            for (int j = 0; j < lim; ++j) {
+                float dot = 0.f;
+                for (int c = 0; c < d; ++c) dot += to_f32(q[(size_t)i * d + c]) * to_f32(k[(size_t)j * d + c]);
+                sc[j] = dot * scale;
+                mx = std::max(mx, sc[j]);
+            }
+            float sum = 0.f;
+            for (int j = 0; j < lim; ++j) { sc[j] = std::exp(sc[j] - mx); sum += sc[j]; }
+            for (int c = 0; c < d; ++c) {
+                float a = 0.f;
+                for (int j = 0; j < lim; ++j) a += sc[j] * to_f32(v[(size_t)j * d + c]);
+                a /= sum;
+                refs.push_back(a);
+                gots.push_back(to_f32(o[(size_t)i * d + c]));
+            }
+        }
+    }
+    // PASS rule: the parity tolerance of the test-suite, |o - ref| <= tol * max(1, max|ref|) with tol 1.6e-2 (bf16) /
+    // 2e-3 (fp16), and the reference harness' symmetric relative error < 0.02 (test_flash_attn.cu:108-143,297-299)
+    // on the elements that are not rounding noise (|ref| >= 10 % of the largest output)
+    double max_ref = 0.0, max_abs = 0.0, max_rel = 0.0;
+    for (float r : refs) max_ref = std::max(max_ref, (double)std::fabs(r));
+    for (size_t i = 0; i < refs.size(); ++i) {
+        const double e = std::fabs((double)refs[i] - gots[i]);
+        max_abs = std::max(max_abs, e);
+        if (std::fabs(refs[i]) >= 0.1 * max_ref) max_rel = std::max(max_rel, e / (std::fabs(refs[i]) + std::fabs(gots[i]) + 1e-5));
+    }
+    const bool pass = max_rel < 0.02 && max_abs <= (bf16 ? 1.6e-2 : 2e-3) * std::max(1.0, max_ref);
+    printf("Verification vs host fp32 attention (2 heads, every %d-th row): max_abs=%.3e max_rel=%.3e -> %s\n",
+           step, max_abs, max_rel, pass ? "PASS" : "FAIL");
+
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) launch();
+    HIP_OK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < runs; ++i) launch();
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= runs;
+    const double bytes = 4.0 * n * 2 + (double)B * H * N * 4;
+    double flops = 4.0 * (double)B * H * (double)N * N * d;
+    if (causal) flops /= 2;
+    printf("\n================================================================================\n");
+    printf("%-25s %10.4f ms\n", "Flash Attention:", ms);
+    printf("%-25s %10.2f GB/s\n", "Flash Throughput:", bytes / (ms * 1e-3) / 1e9);
+    printf("%-25s %10.3f GFLOPs/s  (%.1f %% of the dense 16-bit MFMA peak)\n", "Flash Compute:", flops / (ms * 1e-3) / 1e9,
+           100.0 * flops / (ms * 1e-3) / 2516.6e12);
+    hipFree(Q); hipFree(K); hipFree(V); hipFree(O); hipFree(lse);
+    return pass ? 0 : 1;
+}

@@ -40,9 +40,15 @@ int launch_bwd(const fa::BwdParams& p, int grid, hipStream_t stream)
 template <class T, int D>
 int run_bwd(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s)
 {
-    int rc = causal ? launch_bwd<T, D, 0, true>(pq, grid_q, s) : launch_bwd<T, D, 0, false>(pq, grid_q, s);
+    int rc = FA_OK;
+#if !defined(FA_BWD_ONLY) || FA_BWD_ONLY == 0      // FA_BWD_ONLY: timing-only builds that launch one of the two kernels
+    rc = causal ? launch_bwd<T, D, 0, true>(pq, grid_q, s) : launch_bwd<T, D, 0, false>(pq, grid_q, s);
     if (rc != FA_OK) return rc;
-    return causal ? launch_bwd<T, D, 1, true>(pk, grid_k, s) : launch_bwd<T, D, 1, false>(pk, grid_k, s);
+#endif
+#if !defined(FA_BWD_ONLY) || FA_BWD_ONLY == 1
+    rc = causal ? launch_bwd<T, D, 1, true>(pk, grid_k, s) : launch_bwd<T, D, 1, false>(pk, grid_k, s);
+#endif
+    return rc;
 }
 
 template <class T, int D>
@@ -50,7 +56,9 @@ int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int
              long long o_sb, long long o_sh, long long o_ss, long long g_sb, long long g_sh, long long g_ss, hipStream_t s)
 {
     constexpr int RPB = 256 / (D / 8);
-    hipLaunchKernelGGL((fa::fa_bwd_prep_kernel<T, D>), dim3((Spad + RPB - 1) / RPB, B * H), dim3(256), 0, s,
+    const long long blocks = (long long)((Spad + RPB - 1) / RPB) * B * H;
+    if (blocks > 0x7FFFFFFFll) return fail(FA_ERR_TOO_LARGE, "backward pre-pass grid too large");
+    hipLaunchKernelGGL((fa::fa_bwd_prep_kernel<T, D>), dim3((unsigned)blocks), dim3(256), 0, s,
                        o, d_o, lse, stats, H, S, Spad, B * H, o_sb, o_sh, o_ss, g_sb, g_sh, g_ss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "backward pre-pass launch failed: %s", hipGetErrorString(e));
@@ -94,7 +102,6 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
         return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
     if (workspace_bytes < fa_bwd_workspace_bytes(B, H, S))
         return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, fa_bwd_workspace_bytes(B, H, S));
-    if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the backward pre-pass");
 
     long long st[8][3];
     const int64_t* given[8] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};

@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict
 {
     constexpr int LPR = D / 8;                      // lanes per row
     constexpr int RPB = 256 / LPR;                  // rows per block
-    const int head = blockIdx.y;
+    const int nblk = (Spad + RPB - 1) / RPB;        // row blocks per head (flattened grid: no 65535 limit on B*H)
+    const int head = blockIdx.x / nblk;
     const int b = head / H, h = head - b * H;
-    const int row = blockIdx.x * RPB + threadIdx.x / LPR;
+    const int row = (blockIdx.x - head * nblk) * RPB + threadIdx.x / LPR;
     const int sub = threadIdx.x % LPR;
     if (row >= Spad) return;
     float acc = 0.f;
@@ -304,11 +305,21 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     // ---- a 32-row block passes through three steps; PAR selects one of two register sets (software pipeline)
     f32x4 t1[NBUF][2][2], t2[NBUF][2][2];          // score accumulators [set][y tile][x tile]
     u32x4 pw[NBUF][2], dsw[NBUF][2];               // packed P and dS: B operands, element 4 yt + e <-> y = 16 yt + 4 lg + e
+#if defined(FA_BWD_ABL_NOEW) || defined(FA_BWD_ABL_NOSC)
+    for (int i = 0; i < NBUF; ++i)
+        for (int xt = 0; xt < 2; ++xt) {
+            pw[i][xt] = dsw[i][xt] = u32x4{(unsigned)lane, 1u, 2u, 3u};
+            for (int yt = 0; yt < 2; ++yt) t1[i][yt][xt] = t2[i][yt][xt] = f32x4{0.f, 1.f, 2.f, 3.f};
+        }
+#endif
 
     // SC: T1 = Y1 . X1^T, T2 = Y2 . X2^T for block `blk` of the tile in ring stage `stage`
     // (`stage` and `blk` are ints or integral constants: constants turn every LDS offset into an immediate)
     auto step_scores = [&] __device__ (auto par_c, auto stage, auto blk) {
         constexpr int PAR = decltype(par_c)::value;
+#if defined(FA_BWD_ABL_NOSC)      // timing-only build
+        return;
+#endif
         const unsigned so = stage * TILE + blk * 32 * ROWB;
 #pragma unroll
         for (int yt = 0; yt < 2; ++yt) {
@@ -341,6 +352,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     auto step_softmax = [&] __device__ (auto mask_c, auto par_c, auto stage, auto blk, int y0) {
         constexpr bool MASK = decltype(mask_c)::value;
         constexpr int PAR = decltype(par_c)::value;
+#if defined(FA_BWD_ABL_NOEW)      // timing-only build
+        return;
+#endif
         // row statistics of the streamed rows (MODE 1): rows 16 yt + 4 lg + 0..3 of the block
         f32x4 lse_y[2], delta_y[2];
         if constexpr (MODE == 1) {
@@ -387,6 +401,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     };
     auto step_grads = [&] __device__ (auto par_c, auto stage, auto blk, auto dt_lo, auto dt_hi) {
         constexpr int PAR = decltype(par_c)::value;
+#if defined(FA_BWD_ABL_NOGR)      // timing-only build
+        return;
+#endif
         const unsigned so = stage * TILE + blk * 32 * ROWB;
 #pragma unroll
         for (int dt = decltype(dt_lo)::value; dt < decltype(dt_hi)::value; ++dt) {
@@ -478,8 +495,12 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
             };
             auto sync_and_issue = [&](int j, int dst_stage) {
                 dma_wait<OPS>();
+#if !defined(FA_BWD_ABL_NOBAR)    // timing-only build without the barrier
                 __syncthreads();
+#endif
+#if !defined(FA_BWD_ABL_NODMA)    // timing-only build without the staging DMA
                 issue_tile(j + 2, dst_stage);
+#endif
             };
             int j = j_begin;
             while (j <= j_end) {

@@ -245,3 +245,42 @@ def test_capi_bwd_errors_and_direct_call():
     bad = list(args)
     bad[4] = null
     assert lib.fa_bwd(*bad, B, H, S, D, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream) == -5
+
+
+# ------------------------------------------------------------------ harness pieces (FA2-triton.py:249-309, 357-376)
+def test_try_max_batch_probe_bounded():
+    """The reference's max-batch probe, bounded so that the shared box is not driven out of memory: every batch
+    up to the bound fits (the reference's default probe shape H=16, N=1024, D=32, fp16, causal)."""
+    from flash_attention_impls_amd.bench_utils import try_max_batch
+    assert try_max_batch(fa.flash_attention, base_B=1, limit_B=48) == 48
+    torch.cuda.reset_peak_memory_stats()
+    q = torch.randn(2, 16, 1024, 32, device="cuda", dtype=torch.float16, requires_grad=True)
+    fa.flash_attention(q, q, q, causal=True).float().pow(2).mean().backward()
+    assert 0 < torch.cuda.max_memory_allocated() < 1 << 30
+
+
+def test_many_heads_backward():
+    """B*H above the 65535 grid.y limit goes through the flattened pre-pass grid."""
+    B, H, S, D = 70, 1000, 16, 64
+    q = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    o = fa.flash_attn(q, q, q, True)
+    o.backward(torch.ones_like(o))
+    torch.cuda.synchronize()
+    assert torch.isfinite(q.grad).all()
+    ref = orc.naive_attention_bwd_f64(*[q.detach()[:1, :2].float().cpu().numpy()] * 3, np.ones((1, 2, S, D)), causal=True)
+    got = q.grad[:1, :2].float().cpu().numpy()
+    assert np.abs(got - (ref[0] + ref[1] + ref[2])).max() < 3e-2
+
+
+def test_native_cli_runs_and_passes():
+    """flash_attention_impls_amd/cli/fa_bench: the Python-free harness over the C ABI (main.cu-style argv)."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(fa.__file__), "cli", "fa_bench")
+    if not os.path.exists(exe):
+        from flash_attention_impls_amd import _build
+        _build.build_cli()
+    for argv in (["1", "8", "512", "64", "5"], ["2", "4", "300", "128", "3", "1", "bf16"]):
+        res = subprocess.run([exe, *argv], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert "PASS" in res.stdout and "GFLOPs/s" in res.stdout
