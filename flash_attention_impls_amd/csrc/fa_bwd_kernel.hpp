@@ -18,7 +18,8 @@
 //            MODE 0: Y1 = K, Y2 = V, X1 = Q, X2 = dO  (T1 = S^T, T2 = dP^T: key on the accumulator row)
 //            MODE 1: Y1 = Q, Y2 = dO, X1 = K, X2 = V  (T1 = S,  T2 = dP : query on the accumulator row)
 //   P  = exp2(T1 * scale*log2e - LSE*log2e)  (LSE from the forward; no running max, no rescale),
-//   dS = P * (T2 - delta)                    (delta from the pre-pass; softmax scale applied in the epilogue)
+//   dS = P * T2', T2' = T2 - delta           (-delta from the pre-pass is the initial value of the T2 accumulator:
+//                                             no subtraction in the loop; softmax scale applied in the epilogue)
 //   the accumulators, packed to 16 bits in register order, ARE the B operands of the gradient products
 //   (same trick as the forward's P): out^T[d][x] += Y^T[d][y] . W[y][x], A = Y^T through ds_read_b64_tr_b16:
 //            MODE 0: dQ^T += K^T . dS^T          MODE 1: dV^T += dO^T . P,  dK^T += Q^T . dS
@@ -40,7 +41,7 @@ struct BwdParams {
     const void* x1; const void* x2;     // stationary operands: MODE 0: Q, dO ; MODE 1: K, V
     const void* y1; const void* y2;     // streamed operands:   MODE 0: K, V  ; MODE 1: Q, dO
     void* out1; void* out2;             // MODE 0: dQ, unused ; MODE 1: dK, dV
-    const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then delta (0 past S)
+    const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then -delta (0 past S)
     int B, H, S;
     int Spad;                           // S rounded up to a multiple of 64
     int bh;                             // B*H
@@ -66,7 +67,7 @@ template <int D> __device__ __forceinline__ int bwd_swz(int row, int ch) {
     else return ch ^ (((row >> 1) & 3) << 1);
 }
 
-// pre-pass: delta[row] = sum_d dO[row][d] * O[row][d] (fp32), lse2[row] = LSE[row] * log2(e); padded rows get (+inf, 0).
+// pre-pass: -delta[row] = -sum_d dO[row][d] * O[row][d] (fp32), lse2[row] = LSE[row] * log2(e); padded rows get (+inf, 0).
 // HBM-bound streaming kernel: D/8 lanes per row, 16-byte loads.
 template <class T, int D>
 __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict__ o, const void* __restrict__ d_o,
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict
             l2 = (l == -INFINITY) ? INFINITY : l * 1.4426950408889634f;      // fully masked row: P = 0
         }
         stats[idx] = l2;
-        stats[(long long)bh * Spad + idx] = acc;
+        stats[(long long)bh * Spad + idx] = -acc;        // stored negated: it seeds the dP accumulators
     }
 }
 
@@ -216,15 +217,17 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
         }
     }
     // MODE 0: the statistics belong to the stationary rows (one pair per lane and x tile)
-    float lse_x[2] = {INFINITY, INFINITY}, delta_x[2] = {0.f, 0.f};
+    float lse_x[2] = {INFINITY, INFINITY}, ndelta_x[2] = {0.f, 0.f};
+    f32x4 nd4_x[2];                                 // -delta of the lane's stationary row, four times: initial T2 accumulator
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
             const int xrow = x0w + 16 * xt + li;
             if (xrow < p.Spad) {
                 lse_x[xt] = p.stats[(long long)head * p.Spad + xrow];
-                delta_x[xt] = p.stats[(long long)(p.bh + head) * p.Spad + xrow];
+                ndelta_x[xt] = p.stats[(long long)(p.bh + head) * p.Spad + xrow];
             }
+            nd4_x[xt] = f32x4{ndelta_x[xt], ndelta_x[xt], ndelta_x[xt], ndelta_x[xt]};
         }
     }
 
@@ -323,7 +326,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
         const unsigned so = stage * TILE + blk * 32 * ROWB;
 #pragma unroll
         for (int yt = 0; yt < 2; ++yt) {
-            if constexpr (!PIPE) t1[PAR][yt][0] = t1[PAR][yt][1] = t2[PAR][yt][0] = t2[PAR][yt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // T2 starts at -delta: of the stationary row (MODE 0, a lane constant) or of the streamed rows 16 yt + 4 lg + 0..3
+            f32x4 nd_y;
+            if constexpr (MODE == 1) nd_y = bitcast<f32x4>(lds_read_b128(sta + (stage * 1024 + (blk * 32 + 16 * yt) * 4 + 256)));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 a1 = lds_read_b128(ra[ks] + (so + yt * 16 * ROWB));
@@ -335,14 +340,15 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
                         // readers of t1/t2 away from these MFMAs
                         if (ks == 0) {
                             T::mfma16_v_first(t1[PAR][yt][xt], a1, xf1[xt][ks]);
-                            T::mfma16_v_first(t2[PAR][yt][xt], a2, xf2[xt][ks]);
+                            T::mfma16_v_init(t2[PAR][yt][xt], a2, xf2[xt][ks], nd_y);
                         } else {
                             T::mfma16_v_acc(t1[PAR][yt][xt], a1, xf1[xt][ks]);
                             T::mfma16_v_acc(t2[PAR][yt][xt], a2, xf2[xt][ks]);
                         }
                     } else {
-                        t1[PAR][yt][xt] = T::mfma16(a1, xf1[xt][ks], t1[PAR][yt][xt]);
-                        t2[PAR][yt][xt] = T::mfma16(a2, xf2[xt][ks], t2[PAR][yt][xt]);
+                        // first k-step: C = 0 / the resident -delta vector (a different register than the destination)
+                        t1[PAR][yt][xt] = T::mfma16(a1, xf1[xt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : t1[PAR][yt][xt]);
+                        t2[PAR][yt][xt] = T::mfma16(a2, xf2[xt][ks], ks == 0 ? nd4_x[xt] : t2[PAR][yt][xt]);
                     }
                 }
             }
@@ -356,14 +362,11 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
         return;
 #endif
         // row statistics of the streamed rows (MODE 1): rows 16 yt + 4 lg + 0..3 of the block
-        f32x4 lse_y[2], delta_y[2];
+        f32x4 lse_y[2];
         if constexpr (MODE == 1) {
 #pragma unroll
-            for (int yt = 0; yt < 2; ++yt) {
-                const unsigned so = stage * 1024 + (blk * 32 + 16 * yt) * 4;
-                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + so));
-                delta_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (so + 256)));
-            }
+            for (int yt = 0; yt < 2; ++yt)
+                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (stage * 1024 + (blk * 32 + 16 * yt) * 4)));
         }
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
@@ -374,7 +377,6 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float l2 = (MODE == 0) ? lse_x[xt] : lse_y[yt][e];
-                    const float dl = (MODE == 0) ? delta_x[xt] : delta_y[yt][e];
                     float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[PAR][yt][xt][e], c, -l2));
                     if constexpr (MASK) {
                         const int yrow = y0 + 16 * yt + 4 * lg + e;
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
                         if (dead) pe = 0.f;
                     }
                     pv[e] = pe;
-                    dv[e] = pe * (t2[PAR][yt][xt][e] - dl);
+                    dv[e] = pe * t2[PAR][yt][xt][e];
                 }
                 if constexpr (MODE == 1) {
                     pw[PAR][xt][2 * yt] = T::pack2(pv[0], pv[1]);
@@ -427,22 +429,38 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
         int stage = 0;
         if constexpr (!PIPE) {
             // two waves per SIMD: the hardware interleaves one wave's matrix steps with its partner's softmax
-            for (int j = j_begin; j < j_end; ++j) {
+            auto sync_and_issue0 = [&](int j, int dst_stage) {
                 dma_wait<OPS>();                      // this wave's pieces of tile j have landed ...
                 __syncthreads();                      // ... every wave's are visible, and tile j-1 is no longer read
-                issue_tile(j + 2, (stage + 2) % NS);
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const int bi = 2 * j + blk;
-                    if (bi >= blk_begin_w && bi < blk_end_w) {
-                        step_scores(IC<0>{}, stage, blk);
-                        if (needs_mask(bi)) step_softmax(std::true_type{}, IC<0>{}, stage, blk, bi * 32);
-                        else step_softmax(std::false_type{}, IC<0>{}, stage, blk, bi * 32);
-                        step_grads(IC<0>{}, stage, blk, IC<0>{}, IC<DT>{});
-                    }
+                issue_tile(j + 2, dst_stage);
+            };
+            auto whole_block = [&] __device__ (auto mask_c, auto st, auto blk, int y0) {
+                step_scores(IC<0>{}, st, blk);
+                step_softmax(mask_c, IC<0>{}, st, blk, y0);
+                step_grads(IC<0>{}, st, blk, IC<0>{}, IC<DT>{});
+            };
+            // one loop form only (a second, specialised loop made the register allocator shuffle and spill the
+            // accumulators between the two): a trip = one turn of the ring, so ring stages and block offsets are
+            // immediates; each block is guarded (in this wave's range? on the diagonal?) by scalar branches
+            auto tile = [&] __device__ (auto st_c, int j) {
+                constexpr int ST = decltype(st_c)::value;
+                sync_and_issue0(j, (ST + 2) % NS);
+                const int b0 = 2 * j, b1 = 2 * j + 1;
+                if (b0 >= blk_begin_w && b0 < blk_end_w) {
+                    if (needs_mask(b0)) whole_block(std::true_type{}, IC<ST>{}, IC<0>{}, b0 * 32);
+                    else whole_block(std::false_type{}, IC<ST>{}, IC<0>{}, b0 * 32);
                 }
-                stage = (stage == NS - 1) ? 0 : stage + 1;
+                if (b1 >= blk_begin_w && b1 < blk_end_w) {
+                    if (needs_mask(b1)) whole_block(std::true_type{}, IC<ST>{}, IC<1>{}, b1 * 32);
+                    else whole_block(std::false_type{}, IC<ST>{}, IC<1>{}, b1 * 32);
+                }
+            };
+            for (int j = j_begin; j < j_end; j += NS) {
+                tile(IC<0>{}, j);
+                if (j + 1 < j_end) tile(IC<1>{}, j + 1);
+                if (j + 2 < j_end) tile(IC<2>{}, j + 2);
             }
+            (void)stage;
         } else {
             // one wave per SIMD: software pipeline over blocks -- iteration i runs the matrix products of scores(i)
             // and grads(i-2) around the softmax of block i-1, all three independent of each other.  Block i reads

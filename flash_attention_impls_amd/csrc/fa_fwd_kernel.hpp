@@ -96,6 +96,9 @@ struct TypeBF16 {
     static __device__ __forceinline__ void mfma16_v_acc(f32x4& d, u32x4 a, u32x4 b) {
         asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
     }
+    static __device__ __forceinline__ void mfma16_v_init(f32x4& d, u32x4 a, u32x4 b, f32x4 c) {   // d = a.b + c
+        asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+    }
 };
 struct TypeF16 {
     static constexpr float kPBias = 6.0f;
@@ -115,6 +118,9 @@ struct TypeF16 {
     }
     static __device__ __forceinline__ void mfma16_v_acc(f32x4& d, u32x4 a, u32x4 b) {
         asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void mfma16_v_init(f32x4& d, u32x4 a, u32x4 b, f32x4 c) {
+        asm("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
     }
 };
 
