@@ -15,7 +15,7 @@ LIB_NAME = "libfa_mi355.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
 SOURCES = [os.path.join(CSRC, "fa_capi.hip"), os.path.join(CSRC, "fa_bwd_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, n) for n in ("fa_fwd_kernel.hpp", "fa_fwd_kernel16.hpp", "fa_bwd_kernel.hpp",
+DEPS = SOURCES + [os.path.join(CSRC, n) for n in ("fa_fwd_kernel.hpp", "fa_fwd_kernel16.hpp", "fa_bwd_kernel.hpp", "fa_bwd_dkdv_kernel.hpp",
                                                   "fa_capi_common.hpp")] + \
     [os.path.join(PKG_DIR, "..", "include", "fa_mi355.h")]
 

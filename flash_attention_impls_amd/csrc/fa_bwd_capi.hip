@@ -12,6 +12,7 @@
 #include "../../include/fa_mi355.h"
 #include "fa_capi_common.hpp"
 #include "fa_bwd_kernel.hpp"
+#include "fa_bwd_dkdv_kernel.hpp"
 
 namespace {
 
@@ -37,6 +38,30 @@ int launch_bwd(const fa::BwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
+// dK / dV: MODE 1 of fa_bwd_kernel.hpp (one wave per SIMD carrying both accumulators).  -DFA_BWD_DKDV_SPLIT selects the
+// wave-specialised workgroups of fa_bwd_dkdv_kernel.hpp instead (measured 7 % slower on cfg3: kept as a tuning option)
+template <class T, int D, bool CAUSAL>
+int launch_dkdv(const fa::BwdParams& p, int grid, hipStream_t stream)
+{
+#if !defined(FA_BWD_DKDV_SPLIT)
+    return launch_bwd<T, D, 1, CAUSAL>(p, grid, stream);
+#else
+    constexpr int lds = fa::dkdv_lds_bytes<D>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "dK/dV kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+#endif
+}
+
 template <class T, int D>
 int run_bwd(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s)
 {
@@ -46,7 +71,7 @@ int run_bwd(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int gr
     if (rc != FA_OK) return rc;
 #endif
 #if !defined(FA_BWD_ONLY) || FA_BWD_ONLY == 1
-    rc = causal ? launch_bwd<T, D, 1, true>(pk, grid_k, s) : launch_bwd<T, D, 1, false>(pk, grid_k, s);
+    rc = causal ? launch_dkdv<T, D, true>(pk, grid_k, s) : launch_dkdv<T, D, false>(pk, grid_k, s);
 #endif
     return rc;
 }

@@ -135,6 +135,9 @@ typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     return *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr);
 }
+__device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr) = v;
+}
 __device__ __forceinline__ u32x2 lds_read_tr16_b64(unsigned addr) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(addr));
     return bitcast<u32x2>(t);
