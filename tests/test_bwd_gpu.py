@@ -284,3 +284,34 @@ def test_native_cli_runs_and_passes():
         res = subprocess.run([exe, *argv], capture_output=True, text=True, timeout=120)
         assert res.returncode == 0, res.stdout + res.stderr
         assert "PASS" in res.stdout and "GFLOPs/s" in res.stdout
+
+
+def test_split_dkdv_build_matches_oracle(tmp_path):
+    """-DFA_BWD_DKDV_SPLIT (wave-specialised dK/dV workgroups) is kept as a tuning option: built here
+    with hipcc and held to the same tolerance; dQ and dV are bitwise those of the default build."""
+    import importlib
+    import os
+    import shutil
+    import subprocess
+    from flash_attention_impls_amd import _build
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    so = str(tmp_path / "libfa_split.so")
+    subprocess.run([_build.hipcc_path(), *_build.HIPCC_FLAGS, "-DFA_BWD_DKDV_SPLIT", "-o", so, *_build.SOURCES],
+                   check=True, capture_output=True)
+    fmod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    default = fa.load_library()
+    variant = fmod.load_library(so)
+    try:
+        for (B, H, S, D, dt, causal) in [(1, 3, 700, 128, "bf16", True), (2, 2, 333, 64, "fp16", False)]:
+            q, k, v, do = rand4(B, H, S, D, DT[dt], seed=S)
+            fmod._lib_handle = default
+            _, dq0, dk0, dv0 = hip_grads(q, k, v, do, causal)
+            fmod._lib_handle = variant
+            _, dq1, dk1, dv1 = hip_grads(q, k, v, do, causal)
+            ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=causal)
+            for got, r, key in ((dq1, ref[0], "dq"), (dk1, ref[1], "dk"), (dv1, ref[2], "dv")):
+                assert_grad_close(got, r, dt, f"split {key}")
+            assert torch.equal(dq0, dq1) and torch.equal(dv0, dv1)
+    finally:
+        fmod._lib_handle = default
