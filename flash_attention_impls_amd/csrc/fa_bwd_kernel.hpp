@@ -424,9 +424,17 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     // ---- main loop: tile j lives in ring stage (j - j_begin) % NS; tile j + 2 is issued behind barrier j
     constexpr int OPS = 2 * CPT + (MODE == 1 ? 1 : 0);   // DMA instructions per tile and wave
     if (j_begin < j_end) {
-        issue_tile(j_begin, 0);
-        issue_tile(j_begin + 1, 1);
+        // MODE 1: the ring stage of the first tile is chosen so that the first tile whose blocks are all in the
+        // steady state (for the workgroup's last wave; earlier waves reach it up to one tile sooner) sits in stage 0,
+        // where the four-tile trips with immediate offsets start
         int stage = 0;
+        if constexpr (PIPE) {
+            const int bb_last = CAUSAL ? ((x0 + (NW - 1) * 32) >> 5) : 0;
+            const int j_fast = (bb_last + 3) >> 1;
+            stage = (NS - ((j_fast - j_begin) & (NS - 1))) & (NS - 1);
+        }
+        issue_tile(j_begin, stage);
+        issue_tile(j_begin + 1, (stage + 1) % NS);
         if constexpr (!PIPE) {
             // two waves per SIMD: the hardware interleaves one wave's matrix steps with its partner's softmax
             auto sync_and_issue0 = [&](int j, int dst_stage) {
