@@ -38,12 +38,13 @@ int launch_bwd(const fa::BwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
-// dK / dV: MODE 1 of fa_bwd_kernel.hpp (one wave per SIMD carrying both accumulators).  -DFA_BWD_DKDV_SPLIT selects the
-// wave-specialised workgroups of fa_bwd_dkdv_kernel.hpp instead (measured 7 % slower on cfg3: kept as a tuning option)
+// dK / dV: wave-specialised workgroups (fa_bwd_dkdv_kernel.hpp: a score wave and a gradient wave per SIMD).
+// -DFA_BWD_DKDV_SINGLE selects MODE 1 of fa_bwd_kernel.hpp instead (one wave per SIMD doing everything: 4-8 % slower
+// on cfg3, kept as a tuning option)
 template <class T, int D, bool CAUSAL>
 int launch_dkdv(const fa::BwdParams& p, int grid, hipStream_t stream)
 {
-#if !defined(FA_BWD_DKDV_SPLIT)
+#if defined(FA_BWD_DKDV_SINGLE)
     return launch_bwd<T, D, 1, CAUSAL>(p, grid, stream);
 #else
     constexpr int lds = fa::dkdv_lds_bytes<D>();

@@ -1,41 +1,30 @@
 // FlashAttention backward for gfx950 -- dK / dV kernel with wave-specialised workgroups.
 //
 // Same products, fragment maps, LDS image and causal rules as MODE 1 of fa_bwd_kernel.hpp (read its header first):
-// a workgroup owns 128 keys and streams the Q / dO tiles of its head.  The difference is who holds what.  There, one
-// wave per SIMD carries both 32x128 f32 accumulators (512 registers) and has no partner to overlap its softmax with.
-// Here the work of a 32-key slice is split between TWO waves that share a SIMD, so both fit 256 registers and the
-// hardware interleaves them, without recomputing anything:
+// a workgroup owns 128 keys and streams the Q / dO tiles of its head.  The difference is who does what.  There, one
+// wave per SIMD runs everything for its 32 keys (scores, softmax, both gradient products: 512 registers) and its
+// instruction stream is effectively serial.  Here the work of a 32-key slice is split between TWO waves that share a
+// SIMD, both within 256 registers, and what one of them issues is what the other one does not:
 //
-//   wave w   (0..3, role P): S = Q K^T, P = exp2(S c - LSE2) [masked], publishes P (16-bit, packed in register order)
-//                            in an LDS mailbox, accumulates dV^T += dO^T P           (K fragments + dV^T in registers)
-//   wave w+4 (role S)      : dP' = dO V^T - delta, reads P from the mailbox, dS = P o dP', accumulates
-//                            dK^T += Q^T dS                                          (V fragments + dK^T in registers)
+//   wave w   (0..3, "score wave")   : S = Q K^T, dP' = dO V^T - delta (K and V fragments in registers),
+//                                     P = exp2(S c - LSE2) [masked], dS = P o dP'; publishes P and dS (16-bit, packed
+//                                     in register order) in an LDS mailbox.  MFMA + all of the VALU work, row reads.
+//   wave w+4 (4..7, "gradient wave"): dV^T += dO^T P, dK^T += Q^T dS (both accumulators in registers).
+//                                     MFMA + transposed LDS reads, no VALU work at all.
 //
-// Both roles keep the 16x16x32 fragment maps of fa_bwd_kernel.hpp, so the mailbox is a lane-to-lane hand-over: lane l
-// of the P wave writes the eight packed words that lane l of the S wave needs (two conflict-free ds_write_b128 /
-// ds_read_b128 per 32-row block).  The S wave runs one tile behind the P wave; the one barrier per tile that publishes
-// a staged tile also publishes the mailbox (double-buffered by tile parity).  Ring: 3 stages -- in phase f the P waves
-// read tile f, the S waves tile f-1, tile f+1 is in flight into the stage tile f-2 just left.
-// dS is formed from the 16-bit P (the P wave's fp32 P never leaves its registers): one more rounding of 2^-9 (bf16)
-// on dK's operand, inside the stated tolerance.  The causal mask is applied by the P wave only (P = 0 gives dS = 0).
+// Nothing is recomputed.  Both roles keep the 16x16x32 fragment maps of fa_bwd_kernel.hpp, so the mailbox is a
+// lane-to-lane hand-over: lane l of the score wave writes the sixteen packed words lane l of the gradient wave needs
+// (four conflict-free 16-byte LDS writes / reads per 32-row block).  The gradient wave runs one 32-row block behind;
+// one barrier per block publishes the mailbox (double-buffered by block parity) and, every second block, a staged
+// tile.  Ring: 3 stages of 64-row tiles -- while the score waves read tile j the gradient waves finish tile j-1 and
+// tile j+1 is in flight into the stage tile j-2 left.
 #pragma once
 #include "fa_bwd_kernel.hpp"
 
 namespace fa {
 
 constexpr int kDkdvStages = 3;
-template <int D> constexpr int dkdv_lds_bytes() { return 2 * kDkdvStages * kBN * D * 2 + kDkdvStages * 1024 + 2 * 4 * 2 * 2048; }
-
-template <class T> __device__ __forceinline__ void unpack2(unsigned w, float& a, float& b) {
-    if constexpr (std::is_same<T, TypeBF16>::value) {
-        a = bitcast<float>(w << 16);
-        b = bitcast<float>(w & 0xffff0000u);
-    } else {
-        const f16x2 h = bitcast<f16x2>(w);
-        a = (float)h[0];
-        b = (float)h[1];
-    }
-}
+template <int D> constexpr int dkdv_lds_bytes() { return 2 * kDkdvStages * kBN * D * 2 + kDkdvStages * 1024 + 2 * 4 * 4096; }
 
 template <class T, int D, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
@@ -47,7 +36,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     constexpr int NS = kDkdvStages;
     constexpr int Y2BASE = NS * TILE;
     constexpr int STBASE = 2 * NS * TILE;      // NS x 1 KiB of row statistics
-    constexpr int MBBASE = STBASE + NS * 1024; // mailbox: [tile parity][pair][block][2 x 1 KiB]
+    constexpr int MBBASE = STBASE + NS * 1024; // mailbox: [block parity][pair][P x0, P x1, dS x0, dS x1][64 lanes x 16 B]
     static_assert(CPT >= 1, "tile too small for the workgroup");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,7 +44,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wave >> 2;                // 0: P wave (S, P, dV)   1: S wave (dP, dS, dK)
+    const int role = wave >> 2;                // 0: score wave, 1: gradient wave
     const int pair = wave & 3;
     const int lane = tid & 63;
     const int li = lane & 15;
@@ -75,12 +64,10 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const int x0w = x0 + pair * 32;            // first key of this wave pair
 
     using elem_t = unsigned short;
-    // role P holds K (x1), role S holds V (x2); both stream Q (y1) and dO (y2)
-    const elem_t* xh = role == 0 ? reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh
-                                 : reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + h * p.x2_sh;
-    const long long x_ss = role == 0 ? p.x1_ss : p.x2_ss;
-    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + h * p.y1_sh;
-    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + h * p.y2_sh;
+    const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh;     // K
+    const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + h * p.x2_sh;     // V
+    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + h * p.y1_sh;     // Q
+    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + h * p.y2_sh;     // dO
 
     // ---- streamed range of the workgroup (tiles) and of this pair (blocks)
     const int nty = (S + kBN - 1) / kBN;
@@ -94,20 +81,6 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
         blk_mask = x0w >> 5;
     }
     if (x0w >= S) { blk_begin_w = 0; blk_end_w = 0; }     // no keys: staging duty only
-
-    // ---- stationary fragments: lane (li, lg) holds X[x0w + 16 xt + li][32 ks + 8 lg .. +7]
-    u32x4 xf[2][KS];
-    {
-        const unsigned x_bytes = (unsigned)(((long long)(S - 1) * x_ss + D) * 2);
-        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(xh), 0, x_bytes, 0x00020000);
-#pragma unroll
-        for (int xt = 0; xt < 2; ++xt) {
-            const int xrow = x0w + 16 * xt + li;
-            const unsigned off = (xrow < S) ? (unsigned)((long long)xrow * x_ss * 2 + lg * 16) : 0x80000000u;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) xf[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + ks * 64, 0, 0);
-        }
-    }
 
     // ---- staging by LDS-DMA (as fa_bwd_kernel.hpp), 8 waves
     const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + D) * 2);
@@ -139,194 +112,192 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             dma16(ry2, __builtin_amdgcn_readfirstlane(piece_base + Y2BASE + ST * TILE + i * PIECE), (unsigned)j * y2_tile_stride + g_y2[i]);
     };
 
-    // ---- LDS read addresses.  Role P reads Q by rows (scores) and dO transposed (dV); role S reads dO by rows (dP)
-    //      and Q transposed (dK): the row-read bases point into one ring, the transposed-read bases into the other.
-    unsigned ra[KS], ta[DT];
+    // ---- LDS addresses: row reads of Q / dO (score wave), transposed reads of Q / dO (gradient wave)
+    unsigned ra[KS], ra2[KS], ta[DT], ta2[DT];
     {
-        const unsigned row_ring = lds_base + (role == 0 ? 0 : Y2BASE);
-        const unsigned tr_ring = lds_base + (role == 0 ? Y2BASE : 0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ra[ks] = row_ring + li * ROWB + bwd_swz<D>(li, 4 * ks + lg) * 16;
+        for (int ks = 0; ks < KS; ++ks) {
+            ra[ks] = lds_base + li * ROWB + bwd_swz<D>(li, 4 * ks + lg) * 16;
+            ra2[ks] = ra[ks] + Y2BASE;
+            asm volatile("" : "+v"(ra2[ks]));           // a register of its own: base + 48 KiB does not fit an immediate
+        }
         const int qq = li >> 2, pp = li & 3;
         const int row = 4 * lg + qq;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) ta[dt] = tr_ring + row * ROWB + bwd_swz<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+        for (int dt = 0; dt < DT; ++dt) {
+            ta[dt] = lds_base + row * ROWB + bwd_swz<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+            ta2[dt] = ta[dt] + Y2BASE;
+            asm volatile("" : "+v"(ta2[dt]));
+        }
     }
-    // statistics of rows 4 lg .. +3 (+16 yt + 32 blk): role P needs LSE2 (first 256 bytes of a slot), role S -delta
-    const unsigned sta = lds_base + STBASE + lg * 16 + (role == 0 ? 0 : 256);
-    // mailbox slot of this lane: [parity][pair][blk][half][lane]
-    const unsigned mbox = lds_base + MBBASE + pair * 4096 + lane * 16;
-
-    f32x4 acc[DT][2];          // role P: dV^T, role S: dK^T   [head_dim tile][key tile]
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt][0] = acc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned sta = lds_base + STBASE + lg * 16;            // statistics of rows 4 lg .. +3 (+16 yt + 32 blk): LSE2, -delta at +256
+    asm volatile("" : "+v"(sta));
+    unsigned mbox = lds_base + MBBASE + pair * 4096 + lane * 16;     // this lane's slot: + parity * 16 KiB + word group * 1 KiB
+    asm volatile("" : "+v"(mbox));
     const float c = p.scale_log2;
 
-    auto grads = [&] __device__ (u32x4 (&w)[2], unsigned so) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-#if defined(FA_BWD_ABL_NOTR)      // timing-only build: no transposed reads
-            const u32x4 a = {ta[dt], so, (unsigned)dt, 1u};
-#else
-            const u32x2 lo = lds_read_tr16_b64(ta[dt] + so);
-            const u32x2 hi = lds_read_tr16_b64(ta[dt] + (so + 16 * ROWB));
-            const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
-#endif
-#pragma unroll
-            for (int xt = 0; xt < 2; ++xt) acc[dt][xt] = T::mfma16(a, w[xt], acc[dt][xt]);
+    // every step starts the same way in both roles: HALF = block of the tile, ST = ring stage of tile i / 2
+    auto open_step = [&] __device__ (auto st_c, auto half_c, int i) {
+        constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
+        if constexpr (HALF == 0) dma_wait<0>();                   // a new tile: this wave's pieces (issued a tile ago) have landed
+        __syncthreads();                                          // publishes the mailbox of block i-1 (and tile i/2), retires block i-2
+        if constexpr (HALF == 0) {
+            if ((i >> 1) + 1 < j_end) issue_tile((i >> 1) + 1, IC<(ST + 1) % NS>{});
         }
     };
-    // role P, one 32-row block: scores -> P -> mailbox -> dV
-    auto block_p = [&] __device__ (auto mask_c, auto st_c, auto blk_c, unsigned mb, int y0) {
-        constexpr bool MASK = decltype(mask_c)::value;
-        constexpr int ST = decltype(st_c)::value, BLK = decltype(blk_c)::value;
-        constexpr unsigned so = ST * TILE + BLK * 32 * ROWB;
-        f32x4 t[2][2];
-        f32x4 lse_y[2];
+    // one trip = one turn of the ring (6 blocks); step i = 2 j_end only drains the gradient waves.  The two roles run
+    // separate loops (separate register sets) with the same sequence of barriers.
+    auto for_all_steps = [&] __device__ (auto&& body) {
+        if (j_begin >= j_end) return;
+        issue_tile(j_begin, IC<0>{});
+        for (int i = 2 * j_begin; i <= 2 * j_end; i += 2 * NS) {
+            body(IC<0>{}, IC<0>{}, i);
+            if (i + 1 <= 2 * j_end) body(IC<0>{}, IC<1>{}, i + 1);
+            if (i + 2 <= 2 * j_end) body(IC<1>{}, IC<0>{}, i + 2);
+            if (i + 3 <= 2 * j_end) body(IC<1>{}, IC<1>{}, i + 3);
+            if (i + 4 <= 2 * j_end) body(IC<2>{}, IC<0>{}, i + 4);
+            if (i + 5 <= 2 * j_end) body(IC<2>{}, IC<1>{}, i + 5);
+        }
+    };
+
+    if (role == 0) {
+        // ================= score waves: S, dP - delta -> P, dS -> mailbox =================
+        // stationary fragments: lane (li, lg) holds X[x0w + 16 xt + li][32 ks + 8 lg .. +7]; rows past S read as zero
+        u32x4 xf1[2][KS], xf2[2][KS];
+        {
+            const unsigned x1_bytes = (unsigned)(((long long)(S - 1) * p.x1_ss + D) * 2);
+            const unsigned x2_bytes = (unsigned)(((long long)(S - 1) * p.x2_ss + D) * 2);
+            __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x1h), 0, x1_bytes, 0x00020000);
+            __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x2h), 0, x2_bytes, 0x00020000);
 #pragma unroll
-        for (int yt = 0; yt < 2; ++yt) {
-            lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4)));
+            for (int xt = 0; xt < 2; ++xt) {
+                const int xrow = x0w + 16 * xt + li;
+                const unsigned o1 = (xrow < S) ? (unsigned)((long long)xrow * p.x1_ss * 2 + lg * 16) : 0x80000000u;
+                const unsigned o2 = (xrow < S) ? (unsigned)((long long)xrow * p.x2_ss * 2 + lg * 16) : 0x80000000u;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#if defined(FA_BWD_ABL_NOROW)     // timing-only build: no row reads
-                const u32x4 a = {ra[ks], so, (unsigned)yt, 1u};
-#else
-                const u32x4 a = lds_read_b128(ra[ks] + (so + yt * 16 * ROWB));
-#endif
-#pragma unroll
-                for (int xt = 0; xt < 2; ++xt)
-                    t[yt][xt] = T::mfma16(a, xf[xt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : t[yt][xt]);
+                for (int ks = 0; ks < KS; ++ks) {
+                    xf1[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r1, o1 + ks * 64, 0, 0);
+                    xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, o2 + ks * 64, 0, 0);
+                }
             }
         }
-        u32x4 pw[2];
-#pragma unroll
-        for (int xt = 0; xt < 2; ++xt) {
-            const int xrow = x0w + 16 * xt + li;
+        auto block_scores = [&] __device__ (auto mask_c, auto st_c, auto blk_c, int y0) {
+            constexpr bool MASK = decltype(mask_c)::value;
+            constexpr int ST = decltype(st_c)::value, BLK = decltype(blk_c)::value;
+            constexpr unsigned so = ST * TILE + BLK * 32 * ROWB;
+            f32x4 t1[2][2], t2[2][2];
+            f32x4 lse_y[2];
 #pragma unroll
             for (int yt = 0; yt < 2; ++yt) {
-                float pv[4];
+                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4)));
+                const f32x4 nd = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4 + 256)));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#if defined(FA_BWD_ABL_NOEXP)     // timing-only build: no exponentials
-                    pv[e] = __builtin_fmaf(t[yt][xt][e], c, -lse_y[yt][e]);
-#else
-                    pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(t[yt][xt][e], c, -lse_y[yt][e]));
-#endif
-                    if constexpr (MASK) {
-                        if (xrow > y0 + 16 * yt + 4 * lg + e) pv[e] = 0.f;          // key > query
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 a1 = lds_read_b128(ra[ks] + (so + yt * 16 * ROWB));
+                    const u32x4 a2 = lds_read_b128(ra2[ks] + (so + yt * 16 * ROWB));
+#pragma unroll
+                    for (int xt = 0; xt < 2; ++xt) {
+                        t1[yt][xt] = T::mfma16(a1, xf1[xt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : t1[yt][xt]);
+                        t2[yt][xt] = T::mfma16(a2, xf2[xt][ks], ks == 0 ? nd : t2[yt][xt]);
                     }
                 }
-                pw[xt][2 * yt] = T::pack2(pv[0], pv[1]);
-                pw[xt][2 * yt + 1] = T::pack2(pv[2], pv[3]);
             }
-        }
-#if !defined(FA_BWD_ABL_NOMBOX)    // timing-only build: no mailbox traffic
-        lds_write_b128(mb + BLK * 2048, pw[0]);
-        lds_write_b128(mb + BLK * 2048 + 1024, pw[1]);
-#endif
-        grads(pw, so);
-    };
-    // role S, one 32-row block: dP - delta -> (mailbox P) -> dS -> dK
-    auto block_s = [&] __device__ (auto st_c, auto blk_c, unsigned mb) {
-        constexpr int ST = decltype(st_c)::value, BLK = decltype(blk_c)::value;
-        constexpr unsigned so = ST * TILE + BLK * 32 * ROWB;
-        f32x4 t[2][2];
+            u32x4 pw[2], dsw[2];
 #pragma unroll
-        for (int yt = 0; yt < 2; ++yt) {
-            const f32x4 nd = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4)));
+            for (int xt = 0; xt < 2; ++xt) {
+                const int xrow = x0w + 16 * xt + li;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#if defined(FA_BWD_ABL_NOROW)
-                const u32x4 a = {ra[ks], so, (unsigned)yt, 1u};
-#else
-                const u32x4 a = lds_read_b128(ra[ks] + (so + yt * 16 * ROWB));
-#endif
+                for (int yt = 0; yt < 2; ++yt) {
+                    float pv[4];
 #pragma unroll
-                for (int xt = 0; xt < 2; ++xt) t[yt][xt] = T::mfma16(a, xf[xt][ks], ks == 0 ? nd : t[yt][xt]);
-            }
-        }
-        u32x4 pin[2], dsw[2];
-#if defined(FA_BWD_ABL_NOMBOX)
-        pin[0] = pin[1] = u32x4{mb, 1u, 2u, 3u};
-#else
-        pin[0] = lds_read_b128(mb + BLK * 2048);
-        pin[1] = lds_read_b128(mb + BLK * 2048 + 1024);
-#endif
-#pragma unroll
-        for (int xt = 0; xt < 2; ++xt)
-#pragma unroll
-            for (int yt = 0; yt < 2; ++yt) {
-                float p0, p1, p2, p3;
-                unpack2<T>(pin[xt][2 * yt], p0, p1);
-                unpack2<T>(pin[xt][2 * yt + 1], p2, p3);
-                dsw[xt][2 * yt] = T::pack2(p0 * t[yt][xt][0], p1 * t[yt][xt][1]);
-                dsw[xt][2 * yt + 1] = T::pack2(p2 * t[yt][xt][2], p3 * t[yt][xt][3]);
-            }
-        grads(dsw, so);
-    };
-
-    // ---- phases: in phase f (tile index) the P waves work on tile f, the S waves on tile f-1
-    auto phase = [&] __device__ (auto st_c, int f) {
-        constexpr int ST = decltype(st_c)::value;                 // ring stage of tile f
-#if !defined(FA_BWD_ABL_NOWAIT)   // timing-only build: how much of the phase is DMA latency?
-        dma_wait<0>();                                            // this wave's pieces of tile f (issued a phase ago) have landed
-#endif
-#if !defined(FA_BWD_ABL_NOBAR)
-        __syncthreads();                                          // tile f and the mailbox of tile f-1 are published; tile f-2 is retired
-#endif
-        if (f + 1 < j_end) issue_tile(f + 1, IC<(ST + 1) % NS>{});
-        if (role == 0) {
-            if (f < j_end) {
-                const unsigned mb = mbox + (f & 1) * 16384;
-                const int b0 = 2 * f, b1 = 2 * f + 1;
-                if (b0 >= blk_begin_w && b0 < blk_end_w) {
-                    if (CAUSAL && b0 == blk_mask) block_p(std::true_type{}, IC<ST>{}, IC<0>{}, mb, b0 * 32);
-                    else block_p(std::false_type{}, IC<ST>{}, IC<0>{}, mb, b0 * 32);
-                }
-                if (b1 >= blk_begin_w && b1 < blk_end_w) {
-                    if (CAUSAL && b1 == blk_mask) block_p(std::true_type{}, IC<ST>{}, IC<1>{}, mb, b1 * 32);
-                    else block_p(std::false_type{}, IC<ST>{}, IC<1>{}, mb, b1 * 32);
+                    for (int e = 0; e < 4; ++e) {
+                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[yt][xt][e], c, -lse_y[yt][e]));
+                        if constexpr (MASK) {
+                            if (xrow > y0 + 16 * yt + 4 * lg + e) pv[e] = 0.f;          // key > query
+                        }
+                    }
+                    pw[xt][2 * yt] = T::pack2(pv[0], pv[1]);
+                    pw[xt][2 * yt + 1] = T::pack2(pv[2], pv[3]);
+                    dsw[xt][2 * yt] = T::pack2(pv[0] * t2[yt][xt][0], pv[1] * t2[yt][xt][1]);
+                    dsw[xt][2 * yt + 1] = T::pack2(pv[2] * t2[yt][xt][2], pv[3] * t2[yt][xt][3]);
                 }
             }
-        } else {
-            if (f > j_begin) {
-                const unsigned mb = mbox + ((f - 1) & 1) * 16384;
-                const int b0 = 2 * f - 2, b1 = 2 * f - 1;
-                if (b0 >= blk_begin_w && b0 < blk_end_w) block_s(IC<(ST + NS - 1) % NS>{}, IC<0>{}, mb);
-                if (b1 >= blk_begin_w && b1 < blk_end_w) block_s(IC<(ST + NS - 1) % NS>{}, IC<1>{}, mb);
+            constexpr unsigned mo = BLK * 16384;                        // mailbox parity = block of the tile
+            lds_write_b128(mbox + mo, pw[0]);
+            lds_write_b128(mbox + (mo + 1024), pw[1]);
+            lds_write_b128(mbox + (mo + 2048), dsw[0]);
+            lds_write_b128(mbox + (mo + 3072), dsw[1]);
+        };
+        for_all_steps([&] __device__ (auto st_c, auto half_c, int i) {
+            constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
+            open_step(st_c, half_c, i);
+            if (i >= blk_begin_w && i < blk_end_w) {
+                if (CAUSAL && i == blk_mask) block_scores(std::true_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
+                else block_scores(std::false_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
             }
-        }
-    };
-    if (j_begin < j_end) {
-        issue_tile(j_begin, IC<0>{});
-        for (int f = j_begin; f <= j_end; f += NS) {              // one trip = one turn of the ring; f = j_end: the S waves' last tile
-            phase(IC<0>{}, f);
-            if (f + 1 <= j_end) phase(IC<1>{}, f + 1);
-            if (f + 2 <= j_end) phase(IC<2>{}, f + 2);
-        }
-    }
-
-    // ---- epilogue: role P stores dV, role S stores dK * scale (layout and stores as fa_bwd_kernel.hpp)
-    {
-        elem_t* oh = role == 0 ? reinterpret_cast<elem_t*>(p.out2) + b * p.o2_sb + h * p.o2_sh
-                               : reinterpret_cast<elem_t*>(p.out1) + b * p.o1_sb + h * p.o1_sh;
-        const long long o_ss = role == 0 ? p.o2_ss : p.o1_ss;
-        const float mult = role == 0 ? 1.0f : p.scale;
+        });
+    } else {
+        // ================= gradient waves: mailbox -> dV^T += dO^T P, dK^T += Q^T dS =================
+        f32x4 acc1[DT][2], acc2[DT][2];            // dK^T, dV^T   [head_dim tile][key tile]
 #pragma unroll
-        for (int xt = 0; xt < 2; ++xt) {
-            const int xrow = x0w + 16 * xt + li;
-            elem_t* orow = oh + (long long)xrow * o_ss;
+        for (int dt = 0; dt < DT; ++dt) acc1[dt][0] = acc1[dt][1] = acc2[dt][0] = acc2[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto block_grads = [&] __device__ (auto st_c, auto blk_c) {
+            constexpr int ST = decltype(st_c)::value, BLK = decltype(blk_c)::value;
+            constexpr unsigned so = ST * TILE + BLK * 32 * ROWB;
+            constexpr unsigned mo = BLK * 16384;
+            u32x4 pw[2], dsw[2];
+            pw[0] = lds_read_b128(mbox + mo);
+            pw[1] = lds_read_b128(mbox + (mo + 1024));
+            dsw[0] = lds_read_b128(mbox + (mo + 2048));
+            dsw[1] = lds_read_b128(mbox + (mo + 3072));
 #pragma unroll
-            for (int dt = 0; dt < DT; dt += 2) {
-                const f32x4 oa = acc[dt][xt], ob = acc[dt + 1][xt];
-                unsigned a0 = T::pack2(oa[0] * mult, oa[1] * mult), a1 = T::pack2(oa[2] * mult, oa[3] * mult);
-                unsigned b0 = T::pack2(ob[0] * mult, ob[1] * mult), b1 = T::pack2(ob[2] * mult, ob[3] * mult);
-                auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-                if (xrow < S) {
-                    const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
-                    *reinterpret_cast<u32x4*>(orow + col) = outv;
+            for (int dt = 0; dt < DT; ++dt) {
+                const u32x2 lo2 = lds_read_tr16_b64(ta2[dt] + so);
+                const u32x2 hi2 = lds_read_tr16_b64(ta2[dt] + (so + 16 * ROWB));
+                const u32x4 a2 = {lo2[0], lo2[1], hi2[0], hi2[1]};
+                const u32x2 lo1 = lds_read_tr16_b64(ta[dt] + so);
+                const u32x2 hi1 = lds_read_tr16_b64(ta[dt] + (so + 16 * ROWB));
+                const u32x4 a1 = {lo1[0], lo1[1], hi1[0], hi1[1]};
+#pragma unroll
+                for (int xt = 0; xt < 2; ++xt) {
+                    acc2[dt][xt] = T::mfma16(a2, pw[xt], acc2[dt][xt]);
+                    acc1[dt][xt] = T::mfma16(a1, dsw[xt], acc1[dt][xt]);
+                }
+            }
+        };
+        for_all_steps([&] __device__ (auto st_c, auto half_c, int i) {
+            constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
+            open_step(st_c, half_c, i);
+            if (i - 1 >= blk_begin_w && i - 1 < blk_end_w) {
+                // block i-1: the other half; of the previous tile when this step opens a tile
+                if constexpr (HALF == 0) block_grads(IC<(ST + NS - 1) % NS>{}, IC<1>{});
+                else block_grads(IC<ST>{}, IC<0>{});
+            }
+        });
+        // epilogue: dK * scale, dV; layout and stores as fa_bwd_kernel.hpp
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            elem_t* oh = which == 0 ? reinterpret_cast<elem_t*>(p.out1) + b * p.o1_sb + h * p.o1_sh
+                                    : reinterpret_cast<elem_t*>(p.out2) + b * p.o2_sb + h * p.o2_sh;
+            const long long o_ss = which == 0 ? p.o1_ss : p.o2_ss;
+            const float mult = which == 0 ? p.scale : 1.0f;
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt) {
+                const int xrow = x0w + 16 * xt + li;
+                elem_t* orow = oh + (long long)xrow * o_ss;
+#pragma unroll
+                for (int dt = 0; dt < DT; dt += 2) {
+                    const f32x4 oa = which == 0 ? acc1[dt][xt] : acc2[dt][xt];
+                    const f32x4 ob = which == 0 ? acc1[dt + 1][xt] : acc2[dt + 1][xt];
+                    unsigned a0 = T::pack2(oa[0] * mult, oa[1] * mult), a1 = T::pack2(oa[2] * mult, oa[3] * mult);
+                    unsigned b0 = T::pack2(ob[0] * mult, ob[1] * mult), b1 = T::pack2(ob[2] * mult, ob[3] * mult);
+                    auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+                    if (xrow < S) {
+                        const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+                        *reinterpret_cast<u32x4*>(orow + col) = outv;
+                    }
                 }
             }
         }
