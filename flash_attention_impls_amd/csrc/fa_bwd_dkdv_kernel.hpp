@@ -16,8 +16,8 @@
 // lane-to-lane hand-over: lane l of the score wave writes the sixteen packed words lane l of the gradient wave needs
 // (four conflict-free 16-byte LDS writes / reads per 32-row block).  The gradient wave runs one 32-row block behind;
 // one barrier per block publishes the mailbox (double-buffered by block parity) and, every second block, a staged
-// tile.  Ring: 3 stages of 64-row tiles -- while the score waves read tile j the gradient waves finish tile j-1 and
-// tile j+1 is in flight into the stage tile j-2 left.
+// tile.  The score wave is software-pipelined on its own: the MFMAs of scores(i+1) are issued beside the softmax of
+// block i.  Ring: 3 stages of 64-row tiles, tile j+2 requested in step 2j+1 into the stage tile j-1 has just left.
 #pragma once
 #include "fa_bwd_kernel.hpp"
 
@@ -136,20 +136,31 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     asm volatile("" : "+v"(mbox));
     const float c = p.scale_log2;
 
-    // every step starts the same way in both roles: HALF = block of the tile, ST = ring stage of tile i / 2
+    // every step starts the same way in both roles: HALF = block of the tile, ST = ring stage of tile i / 2.
+    // The score waves run one block ahead with their matrix products (scores(i+1) beside softmax(i)), so tile j+1 has
+    // to be visible from step 2j+1 on: the odd steps wait for it and, behind the barrier, send tile j+2 on its way into
+    // the stage tile j-1 left when the gradient waves finished block 2j-1 in step 2j.
+    constexpr int OPS = 2 * CPT;                                  // DMA instructions per tile and wave (wave 0: one more, issued first)
     auto open_step = [&] __device__ (auto st_c, auto half_c, int i) {
         constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
-        if constexpr (HALF == 0) dma_wait<0>();                   // a new tile: this wave's pieces (issued a tile ago) have landed
-        __syncthreads();                                          // publishes the mailbox of block i-1 (and tile i/2), retires block i-2
-        if constexpr (HALF == 0) {
-            if ((i >> 1) + 1 < j_end) issue_tile((i >> 1) + 1, IC<(ST + 1) % NS>{});
+        if constexpr (HALF == 1) dma_wait<0>();                   // tile i/2 + 1 (issued a tile ago) has landed
+#if !defined(FA_BWD_ABL_NOBAR)     // timing-only build without the barrier
+        __syncthreads();                                          // publishes the mailbox of block i-1 (and tile i/2 + 1), retires block i-2
+#endif
+        if constexpr (HALF == 1) {
+            if ((i >> 1) + 2 < j_end) issue_tile((i >> 1) + 2, IC<(ST + 2) % NS>{});
         }
     };
     // one trip = one turn of the ring (6 blocks); step i = 2 j_end only drains the gradient waves.  The two roles run
-    // separate loops (separate register sets) with the same sequence of barriers.
-    auto for_all_steps = [&] __device__ (auto&& body) {
+    // separate loops (separate register sets) with the same sequence of barriers: one in the prologue (tile j_begin
+    // published; the score waves compute their first scores behind it), then one per step.
+    auto for_all_steps = [&] __device__ (auto&& prologue, auto&& body) {
         if (j_begin >= j_end) return;
         issue_tile(j_begin, IC<0>{});
+        issue_tile(j_begin + 1, IC<1>{});
+        dma_wait<OPS>();                                          // tile j_begin has landed (tile j_begin + 1 stays in flight)
+        __syncthreads();
+        prologue();
         for (int i = 2 * j_begin; i <= 2 * j_end; i += 2 * NS) {
             body(IC<0>{}, IC<0>{}, i);
             if (i + 1 <= 2 * j_end) body(IC<0>{}, IC<1>{}, i + 1);
@@ -181,15 +192,13 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                 }
             }
         }
-        auto block_scores = [&] __device__ (auto mask_c, auto st_c, auto blk_c, int y0) {
-            constexpr bool MASK = decltype(mask_c)::value;
+        f32x4 t1[2][2][2], t2[2][2][2];            // score accumulators [block parity][y tile][x tile]
+        // S and dP - delta of block BLK of the tile in ring stage ST, into register set BLK
+        auto scores = [&] __device__ (auto st_c, auto blk_c) {
             constexpr int ST = decltype(st_c)::value, BLK = decltype(blk_c)::value;
             constexpr unsigned so = ST * TILE + BLK * 32 * ROWB;
-            f32x4 t1[2][2], t2[2][2];
-            f32x4 lse_y[2];
 #pragma unroll
             for (int yt = 0; yt < 2; ++yt) {
-                lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4)));
                 const f32x4 nd = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4 + 256)));
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -197,11 +206,19 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     const u32x4 a2 = lds_read_b128(ra2[ks] + (so + yt * 16 * ROWB));
 #pragma unroll
                     for (int xt = 0; xt < 2; ++xt) {
-                        t1[yt][xt] = T::mfma16(a1, xf1[xt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : t1[yt][xt]);
-                        t2[yt][xt] = T::mfma16(a2, xf2[xt][ks], ks == 0 ? nd : t2[yt][xt]);
+                        t1[BLK][yt][xt] = T::mfma16(a1, xf1[xt][ks], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : t1[BLK][yt][xt]);
+                        t2[BLK][yt][xt] = T::mfma16(a2, xf2[xt][ks], ks == 0 ? nd : t2[BLK][yt][xt]);
                     }
                 }
             }
+        };
+        // P, dS of block BLK (register set BLK) -> mailbox[BLK]
+        auto softmax = [&] __device__ (auto mask_c, auto st_c, auto blk_c, int y0) {
+            constexpr bool MASK = decltype(mask_c)::value;
+            constexpr int ST = decltype(st_c)::value, BLK = decltype(blk_c)::value;
+            f32x4 lse_y[2];
+#pragma unroll
+            for (int yt = 0; yt < 2; ++yt) lse_y[yt] = bitcast<f32x4>(lds_read_b128(sta + (ST * 1024 + (BLK * 32 + 16 * yt) * 4)));
             u32x4 pw[2], dsw[2];
 #pragma unroll
             for (int xt = 0; xt < 2; ++xt) {
@@ -211,15 +228,15 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     float pv[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[yt][xt][e], c, -lse_y[yt][e]));
+                        pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[BLK][yt][xt][e], c, -lse_y[yt][e]));
                         if constexpr (MASK) {
                             if (xrow > y0 + 16 * yt + 4 * lg + e) pv[e] = 0.f;          // key > query
                         }
                     }
                     pw[xt][2 * yt] = T::pack2(pv[0], pv[1]);
                     pw[xt][2 * yt + 1] = T::pack2(pv[2], pv[3]);
-                    dsw[xt][2 * yt] = T::pack2(pv[0] * t2[yt][xt][0], pv[1] * t2[yt][xt][1]);
-                    dsw[xt][2 * yt + 1] = T::pack2(pv[2] * t2[yt][xt][2], pv[3] * t2[yt][xt][3]);
+                    dsw[xt][2 * yt] = T::pack2(pv[0] * t2[BLK][yt][xt][0], pv[1] * t2[BLK][yt][xt][1]);
+                    dsw[xt][2 * yt + 1] = T::pack2(pv[2] * t2[BLK][yt][xt][2], pv[3] * t2[BLK][yt][xt][3]);
                 }
             }
             constexpr unsigned mo = BLK * 16384;                        // mailbox parity = block of the tile
@@ -228,14 +245,38 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             lds_write_b128(mbox + (mo + 2048), dsw[0]);
             lds_write_b128(mbox + (mo + 3072), dsw[1]);
         };
-        for_all_steps([&] __device__ (auto st_c, auto half_c, int i) {
-            constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
-            open_step(st_c, half_c, i);
-            if (i >= blk_begin_w && i < blk_end_w) {
-                if (CAUSAL && i == blk_mask) block_scores(std::true_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
-                else block_scores(std::false_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
-            }
-        });
+        for_all_steps(
+            [&] __device__ () {                                     // first scores (block 2 j_begin, stage 0) behind the prologue barrier
+                const int i0 = 2 * j_begin;
+                if (i0 >= blk_begin_w && i0 < blk_end_w) scores(IC<0>{}, IC<0>{});
+            },
+            [&] __device__ (auto st_c, auto half_c, int i) {
+                constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
+                open_step(st_c, half_c, i);
+#if defined(FA_BWD_ABL_NOSCORE)    // timing-only build: idle score waves
+                return;
+#endif
+                // scores of block i+1 (same tile, or the first block of the next one) beside the softmax of block i:
+                // two independent instruction streams for the scheduler and the hardware
+                const bool do_sc = i + 1 >= blk_begin_w && i + 1 < blk_end_w;
+                const bool do_sm = i >= blk_begin_w && i < blk_end_w;
+                auto next_scores = [&] __device__ () {
+                    if constexpr (HALF == 0) scores(IC<ST>{}, IC<1>{});
+                    else scores(IC<(ST + 1) % NS>{}, IC<0>{});
+                };
+                if (do_sc && do_sm && !(CAUSAL && i == blk_mask)) {          // steady state: one straight-line region
+                    __builtin_amdgcn_sched_barrier(0);       // (also keeps the compiler from folding this path into the guarded one)
+                    next_scores();
+                    softmax(std::false_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    if (do_sc) next_scores();
+                    if (do_sm) {
+                        if (CAUSAL && i == blk_mask) softmax(std::true_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
+                        else softmax(std::false_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
+                    }
+                }
+            });
     } else {
         // ================= gradient waves: mailbox -> dV^T += dO^T P, dK^T += Q^T dS =================
         f32x4 acc1[DT][2], acc2[DT][2];            // dK^T, dV^T   [head_dim tile][key tile]
@@ -265,15 +306,20 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                 }
             }
         };
-        for_all_steps([&] __device__ (auto st_c, auto half_c, int i) {
-            constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
-            open_step(st_c, half_c, i);
-            if (i - 1 >= blk_begin_w && i - 1 < blk_end_w) {
-                // block i-1: the other half; of the previous tile when this step opens a tile
-                if constexpr (HALF == 0) block_grads(IC<(ST + NS - 1) % NS>{}, IC<1>{});
-                else block_grads(IC<ST>{}, IC<0>{});
-            }
-        });
+        for_all_steps(
+            [&] __device__ () {},
+            [&] __device__ (auto st_c, auto half_c, int i) {
+                constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
+                open_step(st_c, half_c, i);
+#if defined(FA_BWD_ABL_NOGRAD)     // timing-only build: idle gradient waves
+                return;
+#endif
+                if (i - 1 >= blk_begin_w && i - 1 < blk_end_w) {
+                    // block i-1: the other half; of the previous tile when this step opens a tile
+                    if constexpr (HALF == 0) block_grads(IC<(ST + NS - 1) % NS>{}, IC<1>{});
+                    else block_grads(IC<ST>{}, IC<0>{});
+                }
+            });
         // epilogue: dK * scale, dV; layout and stores as fa_bwd_kernel.hpp
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
