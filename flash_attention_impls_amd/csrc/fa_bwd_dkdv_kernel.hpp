@@ -191,6 +191,15 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, o2 + ks * 64, 0, 0);
                 }
             }
+            // consume the loads HERE, before any LDS-DMA is in flight: hipcc does not see the asm DMAs, and the vmcnt
+            // waits it would otherwise place at the fragments' first uses inside the loop would drain them every block
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    asm volatile("" : "+v"(xf1[xt][ks]));
+                    asm volatile("" : "+v"(xf2[xt][ks]));
+                }
         }
         f32x4 t1[2][2][2], t2[2][2][2];            // score accumulators [block parity][y tile][x tile]
         // S and dP - delta of block BLK of the tile in ring stage ST, into register set BLK

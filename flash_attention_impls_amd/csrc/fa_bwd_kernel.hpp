@@ -231,6 +231,19 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
         }
     }
 
+    // consume every register load HERE, before any LDS-DMA of this pass is in flight: hipcc does not see the asm DMAs,
+    // and the vmcnt waits it would otherwise place at first uses inside the tile loop would drain them
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            asm volatile("" : "+v"(xf1[xt][ks]));
+            asm volatile("" : "+v"(xf2[xt][ks]));
+        }
+        asm volatile("" : "+v"(lse_x[xt]));
+        asm volatile("" : "+v"(nd4_x[xt]));
+    }
+
     // ---- staging by LDS-DMA: piece (wave * CPT + i) of a tile, swizzle applied on the source address
     const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + D) * 2);
     const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + D) * 2);
