@@ -237,11 +237,20 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     for (int xt = 0; xt < 2; ++xt) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            asm volatile("" : "+v"(xf1[xt][ks]));
-            asm volatile("" : "+v"(xf2[xt][ks]));
+            if constexpr (PIPE) {
+                // MODE 1 reads them as accumulator-file operands of the asm score MFMAs: pin them there (a copy made
+                // right in front of an asm MFMA would not get its v_accvgpr_write -> MFMA wait states)
+                asm volatile("" : "+a"(xf1[xt][ks]));
+                asm volatile("" : "+a"(xf2[xt][ks]));
+            } else {
+                asm volatile("" : "+v"(xf1[xt][ks]));
+                asm volatile("" : "+v"(xf2[xt][ks]));
+            }
         }
-        asm volatile("" : "+v"(lse_x[xt]));
-        asm volatile("" : "+v"(nd4_x[xt]));
+        if constexpr (MODE == 0) {
+            asm volatile("" : "+v"(lse_x[xt]));
+            asm volatile("" : "+v"(nd4_x[xt]));
+        }
     }
 
     // ---- staging by LDS-DMA: piece (wave * CPT + i) of a tile, swizzle applied on the source address
