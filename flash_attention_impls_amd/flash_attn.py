@@ -43,6 +43,31 @@ _lib_lock = threading.Lock()
 _lib_handle = None
 
 
+class _trace_range:
+    """Marker range around a launch, like the reference's NVTX ranges "FA2_FWD" / "FA2_BWD"
+    (FA2-triton.py:186,201,218,236).  On ROCm ``torch.cuda.nvtx`` maps to roctx, which rocprofv3 records with
+    ``--marker-trace``.  Off unless FA_MI355_TRACE=1: the push/pop pair costs a few microseconds per call."""
+    enabled = os.environ.get("FA_MI355_TRACE", "0") == "1"
+
+    def __init__(self, name: str):
+        self.name = name
+        self.pushed = False
+
+    def __enter__(self):
+        if _trace_range.enabled:
+            try:
+                torch.cuda.nvtx.range_push(self.name)
+                self.pushed = True
+            except Exception:  # noqa: BLE001  (markers are best effort: a torch build without roctx just skips them)
+                self.pushed = False
+        return self
+
+    def __exit__(self, *exc):
+        if self.pushed:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 def _declare(lib):
     c = ctypes
     lib.fa_version.restype = c.c_int
@@ -167,7 +192,7 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     if B * H * N == 0:
         return o, lse
     dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
-    with torch.cuda.device(q.device):
+    with torch.cuda.device(q.device), _trace_range("FA2_FWD"):
         stream = torch.cuda.current_stream().cuda_stream
         lse_ptr = lse.data_ptr() if lse is not None else None
         if code == FA_DTYPE_FP8_E4M3:
@@ -193,7 +218,7 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     if B * H * N == 0:
         return dq, dk, dv
     do = _kernel_ready(do.to(q.dtype))
-    with torch.cuda.device(q.device):
+    with torch.cuda.device(q.device), _trace_range("FA2_BWD"):
         stream = torch.cuda.current_stream().cuda_stream
         nbytes = lib.fa_bwd_workspace_bytes(B, H, N)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)

@@ -190,3 +190,25 @@ def test_autograd_function_mirrors_reference_class():
     q = torch.randn(1, 1, 8, 64, requires_grad=True)
     with pytest.raises(AssertionError):
         fa.flash_attn(q, q, q)
+
+
+def test_trace_ranges_are_optional_and_named_like_the_reference(monkeypatch):
+    """FA2_FWD / FA2_BWD marker ranges (FA2-triton.py:186,218) exist, are off by default, and never raise."""
+    import importlib
+    fmod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    src = open(fmod.__file__).read()
+    assert '_trace_range("FA2_FWD")' in src and '_trace_range("FA2_BWD")' in src
+    assert fmod._trace_range.enabled is False
+    calls = []
+    monkeypatch.setattr(fmod._trace_range, "enabled", True)
+    monkeypatch.setattr(torch.cuda.nvtx, "range_push", lambda name: calls.append(("push", name)))
+    monkeypatch.setattr(torch.cuda.nvtx, "range_pop", lambda: calls.append(("pop",)))
+    with fmod._trace_range("FA2_FWD"):
+        pass
+    assert calls == [("push", "FA2_FWD"), ("pop",)]
+
+    def boom(name):
+        raise RuntimeError("no roctx")
+    monkeypatch.setattr(torch.cuda.nvtx, "range_push", boom)
+    with fmod._trace_range("FA2_BWD"):          # best effort: swallowed
+        pass
