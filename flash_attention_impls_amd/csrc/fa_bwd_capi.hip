@@ -78,14 +78,14 @@ int run_bwd(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int gr
 }
 
 template <class T, int D>
-int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int B, int H, int S, int Spad,
+int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int B, int H, int S, int Spad, int dv,
              long long o_sb, long long o_sh, long long o_ss, long long g_sb, long long g_sh, long long g_ss, hipStream_t s)
 {
     constexpr int RPB = 256 / (D / 8);
     const long long blocks = (long long)((Spad + RPB - 1) / RPB) * B * H;
     if (blocks > 0x7FFFFFFFll) return fail(FA_ERR_TOO_LARGE, "backward pre-pass grid too large");
     hipLaunchKernelGGL((fa::fa_bwd_prep_kernel<T, D>), dim3((unsigned)blocks), dim3(256), 0, s,
-                       o, d_o, lse, stats, H, S, Spad, B * H, o_sb, o_sh, o_ss, g_sb, g_sh, g_ss);
+                       o, d_o, lse, stats, H, S, Spad, B * H, dv, o_sb, o_sh, o_ss, g_sb, g_sh, g_ss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "backward pre-pass launch failed: %s", hipGetErrorString(e));
     return FA_OK;
@@ -120,8 +120,9 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     g_err[0] = 0;
     if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16)
         return fail(FA_ERR_BAD_DTYPE, "backward supports bf16 and fp16 (dtype code %d)", dtype);
-    if (D != 64 && D != 128)
-        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (compiled: 64, 128)", D);
+    if (D < 16 || D > 128 || D % 16 != 0)
+        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 128)", D);
+    const bool big = D > 64;                 // head_dim-128 kernels, otherwise the head_dim-64 ones (columns past D read as zeros)
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;
     if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !workspace)
@@ -155,17 +156,17 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
 
     int rc;
     if (dtype == FA_DTYPE_BF16)
-        rc = D == 128 ? run_prep<fa::TypeBF16, 128>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
-                      : run_prep<fa::TypeBF16, 64>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
+        rc = big ? run_prep<fa::TypeBF16, 128>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
+                      : run_prep<fa::TypeBF16, 64>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
     else
-        rc = D == 128 ? run_prep<fa::TypeF16, 128>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
-                      : run_prep<fa::TypeF16, 64>(o, d_o, lse, stats, B, H, S, Spad, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
+        rc = big ? run_prep<fa::TypeF16, 128>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
+                      : run_prep<fa::TypeF16, 64>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
     if (rc != FA_OK) return rc;
 
     fa::BwdParams pq;
     memset(&pq, 0, sizeof(pq));
     pq.stats = stats;
-    pq.B = B; pq.H = H; pq.S = S; pq.Spad = Spad; pq.bh = B * H;
+    pq.B = B; pq.H = H; pq.S = S; pq.dv = D; pq.Spad = Spad; pq.bh = B * H;
     pq.scale = scale;
     pq.scale_log2 = scale * 1.4426950408889634f;
     fa::BwdParams pk = pq;
@@ -193,8 +194,8 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     const bool c = causal != 0;
     if (dtype == FA_DTYPE_BF16)
-        return D == 128 ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
-    return D == 128 ? run_bwd<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
+        return big ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
+    return big ? run_bwd<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
 }
 
 }  // extern "C"

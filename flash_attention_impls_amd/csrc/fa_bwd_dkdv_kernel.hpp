@@ -83,8 +83,8 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     if (x0w >= S) { blk_begin_w = 0; blk_end_w = 0; }     // no keys: staging duty only
 
     // ---- staging by LDS-DMA (as fa_bwd_kernel.hpp), 8 waves
-    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + D) * 2);
-    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + D) * 2);
+    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + p.dv) * 2);
+    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + p.dv) * 2);
     const u32x4 ry1 = make_rsrc(y1h, y1_bytes);
     const u32x4 ry2 = make_rsrc(y2h, y2_bytes);
     unsigned g_y1[CPT], g_y2[CPT];
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     for (int i = 0; i < CPT; ++i) {
         const int byte = (wave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
-        g_y1[i] = (unsigned)(row * p.y1_ss * 2 + bwd_swz<D>(row, chp) * 16);
-        g_y2[i] = (unsigned)(row * p.y2_ss * 2 + bwd_swz<D>(row, chp) * 16);
+        const bool live = bwd_swz<D>(row, chp) * 8 < p.dv;       // chunks past the valid head_dim: out of the descriptor -> zeros
+        g_y1[i] = live ? (unsigned)(row * p.y1_ss * 2 + bwd_swz<D>(row, chp) * 16) : 0x80000000u;
+        g_y2[i] = live ? (unsigned)(row * p.y2_ss * 2 + bwd_swz<D>(row, chp) * 16) : 0x80000000u;
     }
     const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
     const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
         // stationary fragments: lane (li, lg) holds X[x0w + 16 xt + li][32 ks + 8 lg .. +7]; rows past S read as zero
         u32x4 xf1[2][KS], xf2[2][KS];
         {
-            const unsigned x1_bytes = (unsigned)(((long long)(S - 1) * p.x1_ss + D) * 2);
-            const unsigned x2_bytes = (unsigned)(((long long)(S - 1) * p.x2_ss + D) * 2);
+            const unsigned x1_bytes = (unsigned)(((long long)(S - 1) * p.x1_ss + p.dv) * 2);
+            const unsigned x2_bytes = (unsigned)(((long long)(S - 1) * p.x2_ss + p.dv) * 2);
             __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x1h), 0, x1_bytes, 0x00020000);
             __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x2h), 0, x2_bytes, 0x00020000);
 #pragma unroll
@@ -187,8 +188,9 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                 const unsigned o2 = (xrow < S) ? (unsigned)((long long)xrow * p.x2_ss * 2 + lg * 16) : 0x80000000u;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    xf1[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r1, o1 + ks * 64, 0, 0);
-                    xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, o2 + ks * 64, 0, 0);
+                    const bool live = 32 * ks + 8 * lg < p.dv;        // columns past the valid head_dim read as zero
+                    xf1[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r1, live ? o1 + ks * 64 : 0x80000000u, 0, 0);
+                    xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, live ? o2 + ks * 64 : 0x80000000u, 0, 0);
                 }
             }
             // consume the loads HERE, before any LDS-DMA is in flight: hipcc does not see the asm DMAs, and the vmcnt
@@ -349,10 +351,8 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                     u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-                    if (xrow < S) {
-                        const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
-                        *reinterpret_cast<u32x4*>(orow + col) = outv;
-                    }
+                    const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+                    if (xrow < S && col < p.dv) *reinterpret_cast<u32x4*>(orow + col) = outv;
                 }
             }
         }

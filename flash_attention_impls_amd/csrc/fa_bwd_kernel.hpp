@@ -43,6 +43,7 @@ struct BwdParams {
     void* out1; void* out2;             // MODE 0: dQ, unused ; MODE 1: dK, dV
     const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then -delta (0 past S)
     int B, H, S;
+    int dv;                             // valid head_dim (multiple of 16, <= the compiled D): columns past it read as zeros, are not stored
     int Spad;                           // S rounded up to a multiple of 64
     int bh;                             // B*H
     int nxb;                            // stationary blocks per head
@@ -72,7 +73,7 @@ template <int D> __device__ __forceinline__ int bwd_swz(int row, int ch) {
 template <class T, int D>
 __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict__ o, const void* __restrict__ d_o,
                                                           const float* __restrict__ lse, float* __restrict__ stats,
-                                                          int H, int S, int Spad, int bh,
+                                                          int H, int S, int Spad, int bh, int dv,
                                                           long long o_sb, long long o_sh, long long o_ss,
                                                           long long g_sb, long long g_sh, long long g_ss)
 {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict
     const int sub = threadIdx.x % LPR;
     if (row >= Spad) return;
     float acc = 0.f;
-    if (row < S) {
+    if (row < S && sub * 8 < dv) {
         const unsigned short* op = reinterpret_cast<const unsigned short*>(o) + b * o_sb + h * o_sh + (long long)row * o_ss + sub * 8;
         const unsigned short* gp = reinterpret_cast<const unsigned short*>(d_o) + b * g_sb + h * g_sh + (long long)row * g_ss + sub * 8;
         const u32x4 ov = *reinterpret_cast<const u32x4*>(op);
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     // ---- stationary fragments: lane (li, lg) holds X[x0w + 16 xt + li][32 ks + 8 lg .. +7]
     u32x4 xf1[2][KS], xf2[2][KS];
     {
-        const unsigned x1_bytes = (unsigned)(((long long)(S - 1) * p.x1_ss + D) * 2);
-        const unsigned x2_bytes = (unsigned)(((long long)(S - 1) * p.x2_ss + D) * 2);
+        const unsigned x1_bytes = (unsigned)(((long long)(S - 1) * p.x1_ss + p.dv) * 2);
+        const unsigned x2_bytes = (unsigned)(((long long)(S - 1) * p.x2_ss + p.dv) * 2);
         __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x1h), 0, x1_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(x2h), 0, x2_bytes, 0x00020000);
 #pragma unroll
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
             const unsigned o2 = (xrow < S) ? (unsigned)((long long)xrow * p.x2_ss * 2 + lg * 16) : 0x80000000u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                xf1[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r1, o1 + ks * 64, 0, 0);
-                xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, o2 + ks * 64, 0, 0);
+                const bool live = 32 * ks + 8 * lg < p.dv;            // columns past the valid head_dim read as zero
+                xf1[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r1, live ? o1 + ks * 64 : 0x80000000u, 0, 0);
+                xf2[xt][ks] = __builtin_amdgcn_raw_buffer_load_b128(r2, live ? o2 + ks * 64 : 0x80000000u, 0, 0);
             }
         }
     }
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     }
 
     // ---- staging by LDS-DMA: piece (wave * CPT + i) of a tile, swizzle applied on the source address
-    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + D) * 2);
-    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + D) * 2);
+    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + p.dv) * 2);
+    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + p.dv) * 2);
     const u32x4 ry1 = make_rsrc(y1h, y1_bytes);
     const u32x4 ry2 = make_rsrc(y2h, y2_bytes);
     unsigned g_y1[CPT], g_y2[CPT];
@@ -263,8 +265,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
     for (int i = 0; i < CPT; ++i) {
         const int byte = (wave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
-        g_y1[i] = (unsigned)(row * p.y1_ss * 2 + bwd_swz<D>(row, chp) * 16);
-        g_y2[i] = (unsigned)(row * p.y2_ss * 2 + bwd_swz<D>(row, chp) * 16);
+        const bool live = bwd_swz<D>(row, chp) * 8 < p.dv;       // chunks past the valid head_dim: out of the descriptor -> zeros
+        g_y1[i] = live ? (unsigned)(row * p.y1_ss * 2 + bwd_swz<D>(row, chp) * 16) : 0x80000000u;
+        g_y2[i] = live ? (unsigned)(row * p.y2_ss * 2 + bwd_swz<D>(row, chp) * 16) : 0x80000000u;
     }
     const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
     const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
@@ -596,10 +599,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>()) void fa_bwd_kernel(const Bw
                 auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                 u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-                if (xrow < S) {
-                    const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
-                    *reinterpret_cast<u32x4*>(orow + col) = outv;
-                }
+                const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+                if (xrow < S && col < p.dv) *reinterpret_cast<u32x4*>(orow + col) = outv;
             }
         }
     };

@@ -130,7 +130,10 @@ const char* fa_last_error(void) { return g_err; }
 int fa_supported(int dtype, int head_dim)
 {
     if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_FP8_E4M3) return 0;
-    return (head_dim == 64 || head_dim == 128) ? 1 : 0;
+    // every head_dim the reference accepts (D % 16 == 0, D <= 128: FA2-triton.py:178; its native dispatcher: 32, 64, 128,
+    // flash_attn_cutlass.cu:530-543): D <= 64 runs on the head_dim-64 kernel, larger on the head_dim-128 kernel, with the
+    // columns past D read as zeros by the hardware's buffer bounds check and never stored
+    return (head_dim >= 16 && head_dim <= 128 && head_dim % 16 == 0) ? 1 : 0;
 }
 
 int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* grid, int* block, int* lds_bytes)
@@ -139,7 +142,7 @@ int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* g
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape");
     if (grid) *grid = grid_for(B, H, S, causal != 0);
     if (block) *block = kThreads;
-    if (lds_bytes) *lds_bytes = (D == 128) ? fa::lds_bytes<128>() : fa::lds_bytes<64>();
+    if (lds_bytes) *lds_bytes = (D > 64) ? fa::lds_bytes<128>() : fa::lds_bytes<64>();
     return FA_OK;
 }
 
@@ -155,10 +158,8 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
         return fail(FA_ERR_BAD_DTYPE, "fp8 inputs need a workspace: call fa_fwd_fp8");
     if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_FP8_E4M3)
         return fail(FA_ERR_BAD_DTYPE, "unknown dtype code %d", dtype);
-    if (D != 64 && D != 128)
-        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (compiled: 64, 128)", D);
     if (!fa_supported(dtype, D))
-        return fail(FA_ERR_BAD_DTYPE, "no kernel compiled for dtype=%d head_dim=%d", dtype, D);
+        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 128)", D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;        // empty problem: nothing to do
     if (!q || !k || !v || !o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
@@ -167,6 +168,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
     p.B = B; p.H = H; p.S = S;
+    p.dv = D;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.bh = B * H;
     if (!set_strides(q_strides, H, S, D, p.q_sb, p.q_sh, p.q_ss) ||
@@ -200,9 +202,9 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool c = causal != 0;
     if (dtype == FA_DTYPE_BF16)
-        return D == 128 ? launch_c<fa::TypeBF16, 128>(p, grid, c, s) : launch_c<fa::TypeBF16, 64>(p, grid, c, s);
+        return D > 64 ? launch_c<fa::TypeBF16, 128>(p, grid, c, s) : launch_c<fa::TypeBF16, 64>(p, grid, c, s);
     if (dtype == FA_DTYPE_FP16)
-        return D == 128 ? launch_c<fa::TypeF16, 128>(p, grid, c, s) : launch_c<fa::TypeF16, 64>(p, grid, c, s);
+        return D > 64 ? launch_c<fa::TypeF16, 128>(p, grid, c, s) : launch_c<fa::TypeF16, 64>(p, grid, c, s);
     return fail(FA_ERR_BAD_DTYPE, "dtype %d not compiled", dtype);
 }
 
@@ -219,7 +221,8 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
                void* workspace, size_t workspace_bytes, void* stream)
 {
     g_err[0] = 0;
-    if (D != 64 && D != 128) return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (compiled: 64, 128)", D);
+    if (!fa_supported(FA_DTYPE_FP8_E4M3, D))
+        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 128)", D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;
     if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");

@@ -46,6 +46,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct FwdParams {
     const void* q; const void* k; const void* v; void* o; float* lse;
     int B, H, S;
+    int dv;                  // valid head_dim (a multiple of 16, <= the kernel's compiled D): columns dv .. D-1 of every
+                             // Q / K / V row are read as zeros (buffer offsets pushed out of range) and not stored in O
     int nqb;                 // ceil(S / 256)
     int bh;                  // B*H
     // element strides (innermost head_dim stride is 1)
@@ -236,9 +238,9 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + h * p.v_sh;
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
-    const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + D) * 2);
-    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + D) * 2);
-    const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + D) * 2);
+    const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * 2);
+    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + p.dv) * 2);
+    const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + p.dv) * 2);
     __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(qh), 0, q_bytes, 0x00020000);
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
             const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + hh * 16) : 0x80000000u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                qf[qi][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 32, 0, 0);
+                qf[qi][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, (16 * ks + 8 * hh < p.dv) ? qoff + ks * 32 : 0x80000000u, 0, 0);
         }
     };
     if (pass == 0) load_q(qb);
@@ -297,8 +299,9 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     for (int i = 0; i < CPT; ++i) {
         const int byte = (wave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
-        g_koff[i] = (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16);
-        g_voff[i] = (unsigned)(row * p.v_ss * 2 + v_swz<D>(row, chp) * 16);
+        // (chunks past the valid head_dim: an offset no tile index brings back into the descriptor -> zeros)
+        g_koff[i] = (k_swz<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16) : 0x80000000u;
+        g_voff[i] = (v_swz<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.v_ss * 2 + v_swz<D>(row, chp) * 16) : 0x80000000u;
     }
     const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * 2);
     const unsigned v_tile_stride = (unsigned)(kBN * p.v_ss * 2);
@@ -874,8 +877,8 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
                 auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                 // after the swap: lanes 0-31: {own a, upper's a} ; lanes 32-63: {lower's b, own b}
                 u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-                if (qrow < S) {
-                    const int col = db * 32 + 8 * g + 8 * hh;
+                const int col = db * 32 + 8 * g + 8 * hh;
+                if (qrow < S && col < p.dv) {
                     *reinterpret_cast<u32x4*>(orow + col) = outv;
                 }
             }

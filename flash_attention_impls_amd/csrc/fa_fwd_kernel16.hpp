@@ -72,9 +72,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + h * p.v_sh;
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
-    const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + D) * 2);
-    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + D) * 2);
-    const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + D) * 2);
+    const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * 2);
+    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + p.dv) * 2);
+    const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + p.dv) * 2);
     __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(qh), 0, q_bytes, 0x00020000);
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
             const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + lg * 16) : 0x80000000u;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                qf[qt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, qoff + ks * 64, 0, 0);
+                qf[qt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, (32 * ks + 8 * lg < p.dv) ? qoff + ks * 64 : 0x80000000u, 0, 0);
         }
     };
     if (pass == 0) load_q(qb);
@@ -119,8 +119,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     for (int i = 0; i < CPT; ++i) {
         const int byte = (wave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
-        g_koff[i] = (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16);
-        g_voff[i] = (unsigned)(row * p.v_ss * 2 + v_swz16(row, chp) * 16);
+        // (chunks past the valid head_dim: an offset no tile index brings back into the descriptor -> zeros)
+        g_koff[i] = (k_swz<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16) : 0x80000000u;
+        g_voff[i] = (v_swz16(row, chp) * 8 < p.dv) ? (unsigned)(row * p.v_ss * 2 + v_swz16(row, chp) * 16) : 0x80000000u;
     }
     const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * 2);
     const unsigned v_tile_stride = (unsigned)(kBN * p.v_ss * 2);
@@ -574,8 +575,8 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
             auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
             // even lg: {own a, (lg+1)'s a} ; odd lg: {(lg-1)'s b, own b}
             u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-            if (qrow < S) {
-                const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+            const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+            if (qrow < S && col < p.dv) {
                 *reinterpret_cast<u32x4*>(orow + col) = outv;
             }
         }

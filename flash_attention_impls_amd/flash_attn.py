@@ -31,7 +31,6 @@ FA_DTYPE_BF16 = 0
 FA_DTYPE_FP16 = 1
 FA_DTYPE_FP8_E4M3 = 2
 
-_SUPPORTED_HEAD_DIMS = (64, 128)
 
 
 class FlashAttnArgumentError(ValueError, AssertionError):
@@ -275,25 +274,17 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     B, H, N, D_in = q.shape
     if softmax_scale is None:
         softmax_scale = 1.0 / math.sqrt(D_in)             # FA2-triton.py:183 (of the caller's head_dim)
-    # Kernels exist for head_dim 64 and 128.  The reference accepts any D % 16 == 0, D <= 128 (:178): other
-    # sizes are zero-padded up to the next compiled size on the host (zeros add nothing to q.k, and the padded
-    # output columns are dropped) -- correct, at the padded size's cost.
-    D = 64 if D_in <= 64 else 128
-    if D != D_in:
-        pad = (0, D - D_in)
-        if code == FA_DTYPE_FP8_E4M3:
-            q, k, v = [torch.nn.functional.pad(t.view(torch.uint8), pad).view(torch.float8_e4m3fn) for t in (q, k, v)]
-        else:
-            q, k, v = [torch.nn.functional.pad(t, pad) for t in (q, k, v)]
+    # Every head_dim the reference accepts (D % 16 == 0, D <= 128, :178) runs natively: the library picks the head_dim-64
+    # or head_dim-128 kernel and the hardware's buffer bounds check supplies zeros for the columns past D (no padded
+    # copies on the host, nothing extra stored).
+    D = D_in
     if not lib.fa_supported(code, D):
-        raise FlashAttnArgumentError(f"no gfx950 kernel compiled for dtype={q.dtype}, head_dim={D}")
+        raise FlashAttnArgumentError(f"no gfx950 kernel for dtype={q.dtype}, head_dim={D}")
     q, k, v = _kernel_ready(q), _kernel_ready(k), _kernel_ready(v)
     if needs_grad:
         o, lse = FlashAttnFn.apply(q, k, v, bool(causal), float(softmax_scale))
     else:
         o, lse = _fwd_raw(lib, q, k, v, bool(causal), float(softmax_scale), descale, return_lse)
-    if D != D_in:
-        o = o[..., :D_in].contiguous()
     if orig_dtype == torch.float32:
         o = o.to(orig_dtype)                              # FA2-triton.py:244
     return (o, lse) if return_lse else o

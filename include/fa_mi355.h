@@ -56,7 +56,8 @@ extern "C" {
 /* Library version (FA_VERSION of the build). */
 int fa_version(void);
 
-/* 1 if (dtype, head_dim) has a compiled kernel, else 0. */
+/* 1 if (dtype, head_dim) is served: dtype as below, head_dim % 16 == 0 and 16 <= head_dim <= 128 (what the reference
+ * accepts, FA2-triton.py:178; head_dim <= 64 runs on the head_dim-64 kernel, larger on the head_dim-128 kernel). */
 int fa_supported(int dtype, int head_dim);
 
 /* Message describing the last error on the calling thread ("" if none). */

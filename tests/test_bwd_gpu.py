@@ -110,7 +110,7 @@ def test_bwd_fp32_inputs_round_trip_through_fp16():
 
 @pytest.mark.parametrize("D", [16, 48, 96])
 def test_bwd_padded_head_dims(D):
-    """D % 16 == 0, D <= 128 (FA2-triton.py:178): zero-padded to a compiled size on the host, scale 1/sqrt(D)."""
+    """D % 16 == 0, D <= 128 (FA2-triton.py:178): run natively on the head_dim-64 / -128 kernels, scale 1/sqrt(D)."""
     q, k, v, do = rand4(1, 2, 130, D, torch.bfloat16, seed=D)
     _, dq, dk, dv = hip_grads(q, k, v, do, True)
     ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=True)
@@ -241,7 +241,7 @@ def test_capi_bwd_errors_and_direct_call():
     assert lib.fa_bwd(*args, B, H, S, D, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n - 1, stream) == -3
     assert b"workspace" in lib.fa_last_error()
     assert lib.fa_bwd(*args, B, H, S, D, *([null] * 8), 2, 1, 0.0, ws.data_ptr(), n, stream) == -1
-    assert lib.fa_bwd(*args, B, H, S, 96, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream) == -2
+    assert lib.fa_bwd(*args, B, H, S, 72, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream) == -2
     bad = list(args)
     bad[4] = null
     assert lib.fa_bwd(*bad, B, H, S, D, *([null] * 8), 1, 1, 0.0, ws.data_ptr(), n, stream) == -5

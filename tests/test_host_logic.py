@@ -41,8 +41,11 @@ def test_supported_matrix():
     lib = fa.load_library()
     assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 3 * 8 * 32 * 4096 * 128 * 2
     for dt in (0, 1, 2):
-        assert lib.fa_supported(dt, 64) == 1 and lib.fa_supported(dt, 128) == 1
-        assert lib.fa_supported(dt, 32) == 0 and lib.fa_supported(dt, 256) == 0
+        # every head_dim the reference accepts: D % 16 == 0, D <= 128 (FA2-triton.py:178; dispatcher 32/64/128)
+        for d in (16, 32, 48, 64, 80, 96, 112, 128):
+            assert lib.fa_supported(dt, d) == 1
+        for d in (0, 8, 24, 72, 144, 256):
+            assert lib.fa_supported(dt, d) == 0
     assert lib.fa_supported(7, 128) == 0
 
 
@@ -55,7 +58,7 @@ def test_capi_error_codes_without_gpu():
     # bad dtype / head_dim / shape / null pointers
     assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 128, null, null, null, null, 9, 0, 0.0, null, null) == -1
     assert b"dtype" in lib.fa_last_error()
-    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 96, null, null, null, null, 0, 0, 0.0, null, null) == -2
+    assert lib.fa_fwd(p, p, p, p, null, 1, 1, 8, 72, null, null, null, null, 0, 0, 0.0, null, null) == -2
     assert b"head_dim" in lib.fa_last_error()
     assert lib.fa_fwd(p, p, p, p, null, -1, 1, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == -3
     assert lib.fa_fwd(null, p, p, p, null, 1, 1, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == -5
@@ -80,7 +83,7 @@ def test_launch_info_geometry():
     assert (g.value, b.value, l.value) == (8 * 32 * 8, 512, 131072)      # cfg3: causal pairs of query blocks; 4-stage K and V rings of 16 KiB tiles
     assert lib.fa_fwd_launch_info(1, 3, 77, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
     assert (g.value, b.value, l.value) == (8, 512, 65536)                # heads padded to 8 XCD groups
-    assert lib.fa_fwd_launch_info(1, 1, 8, 48, 0, 0, None, None, None) == -2
+    assert lib.fa_fwd_launch_info(1, 1, 8, 40, 0, 0, None, None, None) == -2
 
 
 def test_python_entry_points_and_error_behaviour():
@@ -168,7 +171,7 @@ def test_capi_bwd_error_codes_without_gpu():
     assert lib.fa_bwd_workspace_bytes(8, 32, 4096) == 2 * 8 * 32 * 4096 * 4
     assert lib.fa_bwd(*nine, 1, 1, 8, 128, *([null] * 8), 2, 0, 0.0, p, n, null) == -1      # fp8: forward only
     assert b"bf16 and fp16" in lib.fa_last_error()
-    assert lib.fa_bwd(*nine, 1, 1, 8, 96, *([null] * 8), 0, 0, 0.0, p, n, null) == -2
+    assert lib.fa_bwd(*nine, 1, 1, 8, 72, *([null] * 8), 0, 0, 0.0, p, n, null) == -2
     assert lib.fa_bwd(*nine, 1, -1, 8, 128, *([null] * 8), 0, 0, 0.0, p, n, null) == -3
     assert lib.fa_bwd(*nine, 1, 1, 8, 128, *([null] * 8), 0, 0, 0.0, p, n - 4, null) == -3
     assert lib.fa_bwd(*([p] * 8 + [null]), 1, 1, 8, 128, *([null] * 8), 0, 0, 0.0, p, n, null) == -5

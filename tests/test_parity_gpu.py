@@ -135,14 +135,39 @@ def test_shape_grid_vs_oracle(B, H, S, D, dt, causal):
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_other_head_dims_of_the_reference(D, dt):
     """Every head_dim the reference accepts (D % 16 == 0, D <= 128, FA2-triton.py:178); the reference's own
-    harness pins D == 32 (:333).  Served by zero-padding to the next compiled size; scale stays 1/sqrt(D)."""
+    harness pins D == 32 (:333).  Served natively by the head_dim-64 / -128 kernels (columns past D come back as
+    zeros from the buffer bounds check: no padded copies); scale stays 1/sqrt(D)."""
     q, k, v = rand_qkv(1, 3, 300, D, DT[dt], seed=D)
     for causal in (False, True):
         o, lse = fa.flash_attn(q, k, v, causal, return_lse=True)
-        assert o.shape == q.shape and o.dtype == q.dtype
+        assert o.shape == q.shape and o.dtype == q.dtype and o.is_contiguous()
         ref, lse_ref = ref_f64(q, k, v, causal)
         assert_close(o, ref, TOL[dt], f"D={D} {dt} causal={causal}")
         assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+def test_small_head_dim_neighbouring_memory_is_untouched_and_ignored():
+    """D < compiled size: the kernel must neither read its zero columns from the neighbouring row nor write past D.
+    q/k/v/o live inside larger buffers filled with NaN / a canary."""
+    B, H, S, D = 1, 2, 130, 32
+    g = torch.Generator().manual_seed(5)
+    big = [torch.full((B, H, S, 64), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    for t in big:
+        t[..., :D] = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
+    q, k, v = [t[..., :D] for t in big]                     # row stride 64 elements, NaN in columns 32..63
+    o = fa.flash_attn(q, k, v, True)
+    ref, _ = ref_f64(q, k, v, True)
+    assert_close(o, ref, TOL["bf16"], "strided D=32 views")
+    # raw C-ABI call writing into a canary-filled output buffer with row stride 64
+    lib = fa.load_library()
+    obuf = torch.full((B, H, S, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    st = lambda t: (ctypes.c_int64 * 3)(*t.stride()[:3])
+    rc = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), obuf.data_ptr(), None, B, H, S, D,
+                    st(q), st(k), st(v), st(obuf), 0, 1, ctypes.c_float(0.0), None, None)
+    assert rc == 0, lib.fa_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(obuf[..., :D], o)
+    assert bool((obuf[..., D:] == 7.0).all())
 
 
 def test_reference_main_configuration():
