@@ -143,6 +143,10 @@ def _dtype_code(dt: torch.dtype) -> int:
 
 
 def _strides3(t: torch.Tensor):
+    """Element strides (batch, head, seq) for the C ABI; None (= NULL = contiguous) skips building the array, which is
+    most of the host-side cost of a small launch."""
+    if t.is_contiguous():
+        return None
     sb, sh, ss, sd = t.stride()
     return (ctypes.c_int64 * 3)(sb, sh, ss)
 
