@@ -316,3 +316,16 @@ def test_single_wave_dkdv_build_matches_default(tmp_path):
             assert torch.equal(dq0, dq1) and torch.equal(dv0, dv1) and torch.equal(dk0, dk1)
     finally:
         fmod._lib_handle = default
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_bwd_head_dim_64_large_against_gpu_sdpa(dt):
+    """head_dim 64 at a larger shape (2,4,2048,64), causal and not, against autograd through fp32 SDPA on the box."""
+    import torch.nn.functional as F
+    q, k, v, do = rand4(2, 4, 2048, 64, DT[dt], seed=21)
+    for causal in (True, False):
+        _, dq, dk, dv = hip_grads(q, k, v, do, causal)
+        qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+        F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal, scale=1 / math.sqrt(64)).backward(do.float())
+        for got, r, key in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
+            assert_grad_close(got, r.cpu().numpy(), dt, f"D=64 causal={causal} {key}")

@@ -21,6 +21,9 @@ CONFIGS = {
     "cfg3fp16": (8, 32, 4096, 128, torch.float16, True),
     "cfg4": (1, 16, 16384, 128, torch.bfloat16, True),
     "ref-bwd": (1, 16, 1024, 64, torch.float16, True),
+    "d64": (8, 32, 4096, 64, torch.bfloat16, True),
+    "d64nc": (8, 32, 4096, 64, torch.bfloat16, False),
+    "ref-main": (1, 16, 1024, 32, torch.float16, True),
 }
 
 
