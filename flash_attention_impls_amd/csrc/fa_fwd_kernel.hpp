@@ -140,6 +140,24 @@ __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
 __device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr) = v;
 }
+__device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
+    *reinterpret_cast<__attribute__((address_space(3))) unsigned*>(addr) = v;
+}
+// Workgroup-wide OR of a per-lane predicate through `nwaves` flag words at LDS address `flags` (which nothing else may
+// touch until every wave has passed the second barrier).  Replaces __syncthreads_or: the device-library version keeps
+// the packed work-item ids alive across the whole kernel for its linear-id computation (two VGPRs, spilled here).
+__device__ __forceinline__ bool wg_any(bool pred, unsigned flags, int wave, int lane, int nwaves) {
+    const bool wave_any = __builtin_amdgcn_ballot_w64(pred) != 0;
+    __syncthreads();
+    if (lane == 0) lds_write_b32(flags + 4 * wave, wave_any ? 1u : 0u);
+    __syncthreads();
+    unsigned any = 0;
+    for (int w = 0; w < nwaves; w += 4) {
+        const u32x4 f = lds_read_b128(flags + 4 * w);
+        any |= f[0] | f[1] | f[2] | f[3];
+    }
+    return __builtin_amdgcn_readfirstlane(any) != 0;
+}
 __device__ __forceinline__ u32x2 lds_read_tr16_b64(unsigned addr) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<__attribute__((address_space(3))) s16x4*>(addr));
     return bitcast<u32x2>(t);
@@ -750,7 +768,9 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     // ---- exact fallback (rare): some row's scores rose too far above its first-block reference.
     // The whole workgroup redoes its query block with a plain per-tile online softmax (running max, rescale).
     dma_wait<0>();                                 // no DMA may still be writing LDS past this point
-    if (__syncthreads_or(!(p_peak < T::kPLimit))) {
+    // (flag words in the last V stage: the next pass's prologue does not write there, and its first later DMA sits
+    // behind a barrier)
+    if (wg_any(!(p_peak < T::kPLimit), lds_base + VBASE + (kStages - 1) * TILE, wave, tid & 63, NWAVES)) {
         constexpr int KO = 0, VO = 2 * TILE;                  // two stages each: K at KO, V at VO
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {

@@ -448,7 +448,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     // A lane's row-sum share below kPLimit bounds every P it produced (all terms are positive); NaN fails the test.
     float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     dma_wait<0>();                                 // no DMA may still be writing LDS past this point
-    if (__syncthreads_or(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit))) {
+    // (flag words in the last V stage: the next pass's prologue does not write there, and its first later DMA sits
+    // behind a barrier)
+    if (wg_any(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit), lds_base + VBASE + (kStages - 1) * TILE, wave, tid & 63, NWAVES)) {
         constexpr int KO = 0, VO = VBASE;                     // two stages each: K at KO, V at VO
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
