@@ -329,3 +329,38 @@ def test_bwd_head_dim_64_large_against_gpu_sdpa(dt):
         F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal, scale=1 / math.sqrt(64)).backward(do.float())
         for got, r, key in ((dq, qf.grad, "dq"), (dk, kf.grad, "dk"), (dv, vf.grad, "dv")):
             assert_grad_close(got, r.cpu().numpy(), dt, f"D=64 causal={causal} {key}")
+
+
+def test_bwd_small_head_dim_inside_larger_buffers():
+    """head_dim 32 tensors that are column slices of 64-wide buffers (row stride 64, NaN in the unused columns): the
+    kernels must take their zero columns from the buffer bounds check, not from the neighbouring memory, and leave the
+    unused columns of the gradient buffers untouched (raw C-ABI call with canary-filled outputs)."""
+    B, H, S, D = 1, 2, 150, 32
+    g = torch.Generator().manual_seed(31)
+
+    def wide(fill):
+        t = torch.full((B, H, S, 64), fill, dtype=torch.bfloat16, device="cuda")
+        return t
+
+    bufs = [wide(float("nan")) for _ in range(4)]
+    for t in bufs:
+        t[..., :D] = torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda()
+    q, k, v, do = [t[..., :D] for t in bufs]
+    o, lse = fa.flash_attn(q, k, v, True, return_lse=True)                 # contiguous (B,H,S,32)
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=True)
+    lib = fa.load_library()
+    outs = [wide(7.0) for _ in range(3)]
+    dq, dk, dv = [t[..., :D] for t in outs]
+    n = lib.fa_bwd_workspace_bytes(B, H, S)
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = lambda t: (ctypes.c_int64 * 3)(*t.stride()[:3])
+    rc = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                    dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, S, D,
+                    st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv),
+                    0, 1, 0.0, ws.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.fa_last_error()
+    torch.cuda.synchronize()
+    for got, r, key in ((dq, ref[0], "dq"), (dk, ref[1], "dk"), (dv, ref[2], "dv")):
+        assert_grad_close(got, r, "bf16", key)
+    for t in outs:
+        assert bool((t[..., D:] == 7.0).all())

@@ -480,3 +480,17 @@ def test_alternative_kernel_builds_match_default(flags, tmp_path):
             assert (o1.float() - o0.float()).abs().max() <= 2 ** -6
     finally:
         fa_mod._lib_handle = default
+
+
+def test_fp8_small_head_dim():
+    """fp8-e4m3 inputs at head_dim 32 (32-byte rows): conversion pre-pass + head_dim-64 kernel, bf16 output."""
+    g = torch.Generator().manual_seed(12)
+    f32 = [torch.randn(1, 2, 200, 32, generator=g) for _ in range(3)]
+    ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q8, k8, v8 = [(t / s).to(torch.float8_e4m3fn).cuda() for t, s in zip(f32, ds)]
+    o = fa.flash_attn(q8, k8, v8, True, descale=ds)
+    assert o.dtype == torch.bfloat16 and o.shape == (1, 2, 200, 32)
+    deq = [t.float().cpu() * s for t, s in zip((q8, k8, v8), ds)]
+    ref, _ = orc.naive_attention_f64(*[t.numpy() for t in deq], causal=True)
+    rel = np.linalg.norm(o.float().cpu().numpy() - ref) / np.linalg.norm(ref)
+    assert rel <= 5e-2, rel
