@@ -1,0 +1,50 @@
+"""GPU: randomly drawn shapes (hypothesis) through the whole path, forward and backward, against the float64 oracle.
+Complements the fixed grids of test_parity_gpu.py / test_bwd_gpu.py: ragged lengths around every tile boundary, every
+head_dim the reference accepts, both dtypes, causal or not, batch*heads not a multiple of the 8 XCD groups."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from conftest import TOL
+from oracle import attn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import flash_attention_impls_amd as fa  # noqa: E402
+
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+shape = st.tuples(st.integers(1, 2), st.integers(1, 5), st.integers(1, 330), st.sampled_from(list(range(16, 129, 16))),
+                  st.sampled_from(["bf16", "fp16"]), st.booleans(), st.integers(0, 2 ** 16))
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(shape)
+def test_forward_random_shapes(case):
+    B, H, S, D, dt, causal, seed = case
+    g = torch.Generator().manual_seed(seed)
+    q, k, v = [torch.randn(B, H, S, D, generator=g).to(DT[dt]).cuda() for _ in range(3)]
+    o, lse = fa.flash_attn(q, k, v, causal, return_lse=True)
+    ref, lse_ref = orc.naive_attention_f64(*[t.float().cpu().numpy() for t in (q, k, v)], causal=causal)
+    got = o.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), case
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max()), case
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(shape)
+def test_backward_random_shapes(case):
+    B, H, S, D, dt, causal, seed = case
+    g = torch.Generator().manual_seed(seed)
+    q, k, v, do = [torch.randn(B, H, S, D, generator=g).to(DT[dt]).cuda() for _ in range(4)]
+    leaves = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    fa.flash_attn(*leaves, causal).backward(do)
+    torch.cuda.synchronize()
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=causal)
+    for leaf, r, key in zip(leaves, ref[:3], ("dq", "dk", "dv")):
+        got = leaf.grad.float().cpu().numpy()
+        assert np.isfinite(got).all(), (case, key)
+        assert np.abs(got - r).max() <= TOL[dt] * max(1.0, np.abs(r).max()), (case, key)
