@@ -364,3 +364,18 @@ def test_bwd_small_head_dim_inside_larger_buffers():
         assert_grad_close(got, r, "bf16", key)
     for t in outs:
         assert bool((t[..., D:] == 7.0).all())
+
+
+@pytest.mark.parametrize("dt,mul", [("bf16", 6.0), ("fp16", 4.0)])
+def test_bwd_large_logits(dt, mul):
+    """Inputs scaled so that the scores reach +-100 and beyond (the forward leaves its fixed-reference fast path and
+    takes the exact fallback for some workgroups): P = exp(s - LSE) stays <= 1 in the backward, no overflow, gradients
+    within tolerance of the float64 oracle."""
+    q, k, v, do = rand4(1, 2, 300, 128, DT[dt], seed=77, mul=mul)
+    do = (do.float() / mul).to(DT[dt])
+    _, dq, dk, dv = hip_grads(q, k, v, do, True)
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=True)
+    for got, r, key in ((dq, ref[0], "dq"), (dk, ref[1], "dk"), (dv, ref[2], "dv")):
+        got = got.float().cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), key
+        assert np.abs(got - r).max() <= 2 * TOL[dt] * max(1.0, np.abs(r).max()), (key, np.abs(got - r).max(), np.abs(r).max())
