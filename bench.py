@@ -41,7 +41,8 @@ WORKLOADS = {
     "cfg4": dict(B=1, H=16, S=16384, D=128, dtype="bf16", causal=True),
     "cfg3nc": dict(B=8, H=32, S=4096, D=128, dtype="bf16", causal=False),
     # BASELINE config 5 per-GPU shard (64 batches over 8 GPUs = 8 per GPU): fp8-e4m3 Q/K/V with per-tensor scales;
-    # round 1 computes it with bf16 MFMAs after an exact fp8->bf16 HIP pre-pass (both inside the timed step)
+    # Q K^T reads the fp8 tensors directly (fp8 MFMA), V goes through an exact fp8->bf16 HIP pre-pass for the bf16
+    # P V product (both inside the timed step)
     "cfg5": dict(B=8, H=32, S=4096, D=128, dtype="fp8", causal=False),
 }
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.float8_e4m3fn}
@@ -223,8 +224,9 @@ def main():
         bytes_rank += 8.0 * B * H * S * D * 2 + B * H * S * 4
     ms_per_step = elapsed / args.steps * 1e3
     value = world * flops_rank / (elapsed / args.steps) / 1e12
-    compute_dtype = "bf16" if w["dtype"] == "fp8" else w["dtype"]     # fp8 inputs are computed with bf16 MFMAs
-    peak = MFMA_PEAK_TFLOPS[compute_dtype]
+    # fp8 inputs: Q K^T on fp8 MFMAs (same rate as bf16 for the non-scaled K=32 form), P V on bf16 MFMAs
+    compute_dtype = "fp8+bf16" if w["dtype"] == "fp8" else w["dtype"]
+    peak = MFMA_PEAK_TFLOPS["bf16" if w["dtype"] == "fp8" else compute_dtype]
     achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
 
     gather = None

@@ -70,6 +70,25 @@ int launch16(const fa::FwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
+// head_dim > 64, fp8 Q and K read natively by fp8 MFMAs, V and O bf16 (fa_fwd_kernel16<TypeBF16, CAUSAL, true>)
+template <bool CAUSAL>
+int launch16_qk8(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::lds_bytes<128>();
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel16<fa::TypeBF16, CAUSAL, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel16<fa::TypeBF16, CAUSAL, true>), dim3(grid), dim3(512), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 template <class T, int D>
 int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
 {
@@ -211,7 +230,12 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 size_t fa_fp8_workspace_bytes(int B, int H, int S, int D)
 {
     if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
-    return (size_t)3 * B * H * S * D * 2;               // bf16 copies of q, k, v
+#if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
+    const size_t copies = 3;
+#else
+    const size_t copies = D > 64 ? 1 : 3;               // head_dim > 64: only V is converted (Q, K feed fp8 MFMAs)
+#endif
+    return copies * B * H * S * D * 2;                  // bf16 copies
 }
 
 int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -234,24 +258,60 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
     const long long rows = (long long)B * H * S;
     const size_t one = (size_t)rows * D * 2;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    long long st[3][3];
     for (int t = 0; t < 3; ++t) {
-        long long sb, sh, ss;
-        if (!set_strides(strd[t], H, S, D, sb, sh, ss)) return fail(FA_ERR_BAD_STRIDE, "bad strides");
-        if (sb % 16 || sh % 16 || ss % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
+        if (!set_strides(strd[t], H, S, D, st[t][0], st[t][1], st[t][2])) return fail(FA_ERR_BAD_STRIDE, "bad strides");
+        if (st[t][0] % 16 || st[t][1] % 16 || st[t][2] % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
             return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
+    }
+    if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the fp8 pre-pass");
+#if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
+    const bool native_qk = false;
+#else
+    // head_dim > 64: Q and K stay fp8 and feed v_mfma_f32_16x16x32_fp8_fp8 directly (half the K bytes through HBM, L2,
+    // LDS-DMA and LDS reads); only V is converted, because P V runs on bf16 MFMAs with P from the fp32 softmax
+    const bool native_qk = D > 64;
+#endif
+    char* w = static_cast<char*>(workspace);
+    const int first = native_qk ? 2 : 0;                // the workspace holds the converted tensors back to back
+    for (int t = first; t < 3; ++t) {
         const int per_slice = S * (D / 16);
         const int bx = std::max(1, std::min((per_slice + 255) / 256, 64));
-        if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the fp8 pre-pass");
         hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(bx, B * H), dim3(256), 0, s,
                            reinterpret_cast<const unsigned char*>(src[t]),
-                           reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + t * one),
-                           D, H, S, sb, sh, ss);
+                           reinterpret_cast<unsigned short*>(w + (t - first) * one),
+                           D, H, S, st[t][0], st[t][1], st[t][2]);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fp8 conversion launch failed: %s", hipGetErrorString(e));
     }
-    char* w = static_cast<char*>(workspace);
-    return fa_fwd(w, w + one, w + 2 * one, o, lse, B, H, S, D, nullptr, nullptr, nullptr, o_strides,
-                  FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
+    if (!native_qk)
+        return fa_fwd(w, w + one, w + 2 * one, o, lse, B, H, S, D, nullptr, nullptr, nullptr, o_strides,
+                      FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
+
+    if (!o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
+    fa::FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = w; p.o = o; p.lse = lse;
+    p.B = B; p.H = H; p.S = S; p.dv = D;
+    p.nqb = (S + fa::kBM - 1) / fa::kBM;
+    p.bh = B * H;
+    p.q_sb = st[0][0]; p.q_sh = st[0][1]; p.q_ss = st[0][2];
+    p.k_sb = st[1][0]; p.k_sh = st[1][1]; p.k_ss = st[1][2];
+    p.v_ss = D; p.v_sh = (long long)S * D; p.v_sb = (long long)H * S * D;
+    if (!set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss)) return fail(FA_ERR_BAD_STRIDE, "bad output strides");
+    if ((p.o_sb * 2) % 16 || (p.o_sh * 2) % 16 || (p.o_ss * 2) % 16 || reinterpret_cast<uintptr_t>(o) % 16)
+        return fail(FA_ERR_BAD_STRIDE, "output rows must be 16-byte aligned");
+    const long long max_ss = std::max(std::max(p.q_ss, p.k_ss), std::max(2 * p.v_ss, 2 * p.o_ss));
+    if (((long long)S + 4 * fa::kBN) * max_ss >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d)", S);
+    const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
+    const float dq = descale ? descale[0] : 1.f, dkk = descale ? descale[1] : 1.f, dvv = descale ? descale[2] : 1.f;
+    p.scale = scale * dq * dkk;
+    p.scale_log2 = p.scale * 1.4426950408889634f;
+    p.out_scale = dvv;
+    const int grid = grid_for(B, H, S, causal != 0);
+    if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
+    return causal ? launch16_qk8<true>(p, grid, s) : launch16_qk8<false>(p, grid, s);
 }
 
 int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,

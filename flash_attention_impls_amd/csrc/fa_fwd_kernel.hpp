@@ -137,6 +137,14 @@ typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
     return *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr);
 }
+__device__ __forceinline__ u32x2 lds_read_b64(unsigned addr) {
+    return *reinterpret_cast<__attribute__((address_space(3))) u32x2*>(addr);
+}
+// S^T tile on fp8 (OCP e4m3) operands: v_mfma_f32_16x16x32_fp8_fp8, lane (i, g) holds A[row i][k = 8 g + 0..7] /
+// B[k = 8 g + 0..7][col i] in the eight bytes of a register pair (the bf16 map with one byte per element)
+__device__ __forceinline__ f32x4 mfma16_fp8(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bitcast<long>(a), bitcast<long>(b), c, 0, 0, 0);
+}
 __device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr) = v;
 }

@@ -34,11 +34,16 @@ namespace fa {
 // XOR the 32-byte segment index with (key & 7) so they fill one 256-byte bank row.
 __device__ __forceinline__ int v_swz16(int row, int ch) { return ch ^ ((row & 7) << 1); }
 
-template <class T, bool CAUSAL>
+// QK8: Q and K are fp8 (OCP e4m3) tensors (element strides = byte strides) and S^T = K Q^T runs on fp8 MFMAs; V (and
+// the P V product, O) stay 16-bit of type T.  The K tile then takes the first half of its ring stage (128-byte rows).
+template <class T, bool CAUSAL, bool QK8 = false>
 __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
 {
     constexpr int D = 128;
     constexpr int NWAVES = 8;
+    constexpr int QKB = QK8 ? 1 : 2;           // bytes per Q / K element
+    constexpr int KROWB = D * QKB;             // bytes per K row in LDS
+    constexpr int CPTK = kBN * KROWB / 1024 / NWAVES;   // K DMA pieces per wave per tile (2, fp8: 1)
     constexpr int KS = D / 32;                 // k-steps of the QK^T product (4)
     constexpr int DT = D / 16;                 // 16-wide head_dim tiles of O^T (8)
     constexpr int ROWB = D * 2;                // bytes per K/V row in LDS
@@ -67,19 +72,20 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
-    const elem_t* qh = reinterpret_cast<const elem_t*>(p.q) + b * p.q_sb + h * p.q_sh;
-    const elem_t* kh = reinterpret_cast<const elem_t*>(p.k) + b * p.k_sb + h * p.k_sh;
+    const char* qh = reinterpret_cast<const char*>(p.q) + (b * p.q_sb + h * p.q_sh) * QKB;
+    const char* kh = reinterpret_cast<const char*>(p.k) + (b * p.k_sb + h * p.k_sh) * QKB;
     const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + h * p.v_sh;
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
-    const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * 2);
-    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + p.dv) * 2);
+    const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * QKB);
+    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + p.dv) * QKB);
     const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + p.dv) * 2);
-    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(qh), 0, q_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qh), 0, q_bytes, 0x00020000);
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
 
-    u32x4 qf[2][KS];           // Q fragments [query tile][k-step] of the current pass
+    u32x4 qf[2][QK8 ? 1 : KS]; // Q fragments [query tile][k-step] of the current pass (16-bit Q)
+    u32x2 qf8[2][QK8 ? KS : 1];    // ... fp8 Q: eight bytes per lane and k-step
 
   for (int pass = 0; pass < n_pass; ++pass) {
     const int qb = CAUSAL ? (pass == 0 ? p.nqb - 1 - tq : tq) : tq;
@@ -104,32 +110,48 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         for (int qt = 0; qt < 2; ++qt) {
             const int qrow = row0 + 16 * qt + li;
             // rows past the end of the sequence get an offset outside the descriptor: they read as zero
-            const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + lg * 16) : 0x80000000u;
+            const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * QKB + lg * 8 * QKB) : 0x80000000u;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qf[qt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, (32 * ks + 8 * lg < p.dv) ? qoff + ks * 64 : 0x80000000u, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned off = (32 * ks + 8 * lg < p.dv) ? qoff + ks * 32 * QKB : 0x80000000u;
+                if constexpr (QK8) qf8[qt][ks] = __builtin_amdgcn_raw_buffer_load_b64(rq, off, 0, 0);
+                else qf[qt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0);
+            }
         }
     };
     if (pass == 0) load_q(qb);
 
     // ---- K/V staging by LDS-DMA (see fa_fwd_kernel.hpp); V uses the 16x16 swizzle
     constexpr int VBASE = kStages * TILE;
-    unsigned g_koff[CPT], g_voff[CPT];
+    unsigned g_koff[CPTK], g_voff[CPT];
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
         const int byte = (wave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
         // (chunks past the valid head_dim: an offset no tile index brings back into the descriptor -> zeros)
-        g_koff[i] = (k_swz<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16) : 0x80000000u;
         g_voff[i] = (v_swz16(row, chp) * 8 < p.dv) ? (unsigned)(row * p.v_ss * 2 + v_swz16(row, chp) * 16) : 0x80000000u;
     }
-    const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * 2);
+#pragma unroll
+    for (int i = 0; i < CPTK; ++i) {
+        const int byte = (wave * CPTK + i) * PIECE + lane * 16;
+        const int row = byte / KROWB, chp = (byte % KROWB) / 16;
+        if constexpr (QK8) {
+            // fp8 K rows are 128 bytes: two rows per 256-byte bank row; 16-byte chunk c of row r lives at chunk
+            // c ^ ((r >> 1) & 7), which spreads the 8-byte fragment reads of 16 rows over all banks
+            const int lc = chp ^ ((row >> 1) & 7);
+            g_koff[i] = (lc * 16 < p.dv) ? (unsigned)(row * p.k_ss + lc * 16) : 0x80000000u;
+        } else {
+            g_koff[i] = (k_swz<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16) : 0x80000000u;
+        }
+    }
+    const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * QKB);
     const unsigned v_tile_stride = (unsigned)(kBN * p.v_ss * 2);
     const unsigned piece_base = lds_base + wave * CPT * PIECE;       // wave-uniform
+    const unsigned kpiece_base = lds_base + wave * CPTK * PIECE;
     auto dma_k = [&](int j, unsigned stage_off) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i)
-            dma16(rk_w, __builtin_amdgcn_readfirstlane(piece_base + stage_off + i * PIECE), (unsigned)j * k_tile_stride + g_koff[i]);
+        for (int i = 0; i < CPTK; ++i)
+            dma16(rk_w, __builtin_amdgcn_readfirstlane(kpiece_base + stage_off + i * PIECE), (unsigned)j * k_tile_stride + g_koff[i]);
     };
     auto dma_v = [&](int j, unsigned stage_off) {
 #pragma unroll
@@ -141,7 +163,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     // K fragment: lane (li,lg) reads K[half*32 + 16 kt + li][32 ks + 8 lg + 0..7] = chunk 4 ks + lg of the row
     unsigned ka[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ka[ks] = lds_base + li * ROWB + k_swz<D>(li, 4 * ks + lg) * 16;
+    for (int ks = 0; ks < KS; ++ks)
+        ka[ks] = QK8 ? lds_base + li * KROWB + ((4 * ks + lg) ^ (((li >> 1) & 7) << 1)) * 8      // 8-byte granule 4 ks + lg of the row
+                     : lds_base + li * ROWB + k_swz<D>(li, 4 * ks + lg) * 16;
     // V^T fragment of head_dim tile dt: lane 4q+pp of a 16-lane group supplies key row 4 lg + q, head_dim
     // columns 16 dt + 4 pp .. +3 (8 bytes); second read 16 keys further down.
     unsigned va[DT];
@@ -154,15 +178,19 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     }
 
     // fragment registers: one group of 4 K fragments, one group of 4 V^T fragments (re-read one group ahead)
-    u32x4 kf[4];
+    u32x4 kf[QK8 ? 1 : 4];
+    u32x2 kf8[QK8 ? 4 : 1];
     u32x4 vf[4];
     // stage_c >= 0: the address registers hold stage-0 bases and the ring stage is an immediate (unrolled loop);
     // stage_c == -1: the address registers already carry the stage of the tile being read
     auto read_kgroup = [&] __device__ (auto stage_c, auto half_c, auto kt_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, kt = decltype(kt_c)::value;
-        constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half + 16 * kt) * ROWB;
+        constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half + 16 * kt) * KROWB;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = lds_read_b128(ka[ks] + off);
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (QK8) kf8[ks] = lds_read_b64(ka[ks] + off);
+            else kf[ks] = lds_read_b128(ka[ks] + off);
+        }
     };
     auto read_vgroup = [&] __device__ (auto stage_c, auto half_c, auto grp_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, grp = decltype(grp_c)::value;
@@ -249,7 +277,8 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
-                s_acc[par][kt][qt] = T::mfma16(kf[ks], qf[qt][ks], s_acc[par][kt][qt]);
+                if constexpr (QK8) s_acc[par][kt][qt] = mfma16_fp8(kf8[ks], qf8[qt][ks], s_acc[par][kt][qt]);
+                else s_acc[par][kt][qt] = T::mfma16(kf[ks], qf[qt][ks], s_acc[par][kt][qt]);
     };
     auto advance = [&](int dk, int dv) {
 #pragma unroll
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         dma_v(1, TILE);
     };
     if (pass == 0) issue_prologue();
-    dma_wait<3 * CPT>();        // this wave's pieces of K(0), V(0) have landed ...
+    dma_wait<2 * CPTK + CPT>(); // this wave's pieces of K(0), V(0) have landed ...
     __syncthreads();            // ... and every wave's are visible
 
     int stage_k = 0;                               // ring stage of tile j
@@ -361,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         dv = (j == 0) ? 0 : ((stage_k == 0) ? -(kStages - 1) * TILE : TILE);   // V(j-1) -> V(j)
     };
     auto sync_and_stage = [&](int j) {             // barrier(j) + DMA of K(j+3), V(j+2)
-        dma_wait<2 * CPT>();                       // everything but the previous iteration's DMA has landed ...
+        dma_wait<CPTK + CPT>();                    // everything but the previous iteration's DMA has landed ...
         __syncthreads();                           // ... and is published; last iteration's reads are done
         dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
         dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
     auto sync_and_stage_c = [&] __device__ (auto st_c, int j) {      // same, ring stage of tile j known at compile time
         constexpr int ST = decltype(st_c)::value;
-        dma_wait<2 * CPT>();
+        dma_wait<CPTK + CPT>();
         __syncthreads();
         dma_k(j + 3, ((ST + 3) & (kStages - 1)) * TILE);
         dma_v(j + 2, ((ST + 2) & (kStages - 1)) * TILE);
@@ -460,7 +489,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         l_part[0] = l_part[1] = 0.f;
         unsigned ka2[KS], va2[DT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) ka2[ks] = lds_base + KO + li * ROWB + k_swz<D>(li, 4 * ks + lg) * 16;
+        for (int ks = 0; ks < KS; ++ks)
+            ka2[ks] = QK8 ? lds_base + KO + li * KROWB + ((4 * ks + lg) ^ (((li >> 1) & 7) << 1)) * 8
+                          : lds_base + KO + li * ROWB + k_swz<D>(li, 4 * ks + lg) * 16;
         {
             const int qq = li >> 2, pp = li & 3;
             const int row = 4 * lg + qq;
@@ -471,10 +502,11 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         auto dma2 = [&](int jj) {
             const unsigned st = (jj & 1) * TILE;
 #pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                dma16(rk_w, __builtin_amdgcn_readfirstlane(piece_base + KO + st + i * PIECE), (unsigned)jj * k_tile_stride + g_koff[i]);
+            for (int i = 0; i < CPTK; ++i)
+                dma16(rk_w, __builtin_amdgcn_readfirstlane(kpiece_base + KO + st + i * PIECE), (unsigned)jj * k_tile_stride + g_koff[i]);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
                 dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VO + st + i * PIECE), (unsigned)jj * v_tile_stride + g_voff[i]);
-            }
         };
         dma2(0);
         for (int jj = 0; jj < nt; ++jj) {
@@ -491,9 +523,15 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
                         sx[kt][0] = sx[kt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) {
-                            const u32x4 kx = lds_read_b128(ka2[ks] + st + (32 * half + 16 * kt) * ROWB);
+                            if constexpr (QK8) {
+                                const u32x2 kx = lds_read_b64(ka2[ks] + st + (32 * half + 16 * kt) * KROWB);
 #pragma unroll
-                            for (int qt = 0; qt < 2; ++qt) sx[kt][qt] = T::mfma16(kx, qf[qt][ks], sx[kt][qt]);
+                                for (int qt = 0; qt < 2; ++qt) sx[kt][qt] = mfma16_fp8(kx, qf8[qt][ks], sx[kt][qt]);
+                            } else {
+                                const u32x4 kx = lds_read_b128(ka2[ks] + st + (32 * half + 16 * kt) * ROWB);
+#pragma unroll
+                                for (int qt = 0; qt < 2; ++qt) sx[kt][qt] = T::mfma16(kx, qf[qt][ks], sx[kt][qt]);
+                            }
                         }
                     }
                     const int key0 = jj * kBN + half * 32;

@@ -85,12 +85,14 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            const float* descale, void* stream);
 
 /*
- * fp8 (OCP e4m3fn) Q/K/V, bf16 O.  Round 1 implementation: the three tensors are converted (exactly) to bf16
- * into the caller-provided device workspace by a HIP pre-pass, then the bf16 kernel runs with the q,k
- * dequantisation scales folded into the softmax scale and the v scale into the output.  No reference
- * counterpart (the reference is fp16 only); BASELINE.json config 5.
+ * fp8 (OCP e4m3fn) Q/K/V, bf16 O.  head_dim > 64: Q and K are consumed as fp8 by the score MFMAs
+ * (v_mfma_f32_16x16x32_fp8_fp8); V is converted (exactly) to bf16 into the caller-provided device workspace by a HIP
+ * pre-pass, because P V runs on bf16 MFMAs with P from the fp32 softmax.  head_dim <= 64: all three tensors are
+ * converted and the bf16 kernel runs.  The q,k dequantisation scales are folded into the softmax scale, the v scale
+ * into the output.  No reference counterpart (the reference is fp16 only); BASELINE.json config 5.
  *   strides are in elements (= bytes) with unit head_dim stride; rows and bases 16-byte aligned.
- *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes, 16-byte aligned.
+ *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes (one bf16 tensor for head_dim > 64,
+ *              three otherwise), 16-byte aligned.
  */
 size_t fa_fp8_workspace_bytes(int B, int H, int S, int D);
 int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,

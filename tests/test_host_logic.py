@@ -39,7 +39,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 
 def test_supported_matrix():
     lib = fa.load_library()
-    assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 3 * 8 * 32 * 4096 * 128 * 2
+    assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 1 * 8 * 32 * 4096 * 128 * 2      # only V is converted
+    assert lib.fa_fp8_workspace_bytes(4, 8, 1024, 64) == 3 * 4 * 8 * 1024 * 64 * 2
     for dt in (0, 1, 2):
         # every head_dim the reference accepts: D % 16 == 0, D <= 128 (FA2-triton.py:178; dispatcher 32/64/128)
         for d in (16, 32, 48, 64, 80, 96, 112, 128):

@@ -494,3 +494,39 @@ def test_fp8_small_head_dim():
     ref, _ = orc.naive_attention_f64(*[t.numpy() for t in deq], causal=True)
     rel = np.linalg.norm(o.float().cpu().numpy() - ref) / np.linalg.norm(ref)
     assert rel <= 5e-2, rel
+
+
+def test_fp8_native_qk_matches_convert_all_build(tmp_path):
+    """head_dim 128 fp8: the default path feeds Q and K to fp8 MFMAs; -DFA_FP8_CONVERT_ALL converts all three tensors to
+    bf16 first (the products are the same exact numbers either way): both within the fp8 tolerance of the oracle and
+    within bf16 rounding of each other."""
+    import importlib
+    import shutil
+    import subprocess
+    from flash_attention_impls_amd import _build
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    so = str(tmp_path / "libfa_convert_all.so")
+    subprocess.run([_build.hipcc_path(), *_build.HIPCC_FLAGS, "-DFA_FP8_CONVERT_ALL", "-o", so, *_build.SOURCES],
+                   check=True, capture_output=True)
+    fa_mod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    default = fa.load_library()
+    variant = fa_mod.load_library(so)
+    g = torch.Generator().manual_seed(3)
+    f32 = [torch.randn(2, 3, 777, 128, generator=g) for _ in range(3)]
+    ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q8, k8, v8 = [(t / s).to(torch.float8_e4m3fn).cuda() for t, s in zip(f32, ds)]
+    deq = [t.float().cpu().numpy() * s for t, s in zip((q8, k8, v8), ds)]
+    try:
+        for causal in (False, True):
+            fa_mod._lib_handle = default
+            o0 = fa.flash_attn(q8, k8, v8, causal, descale=ds)
+            fa_mod._lib_handle = variant
+            o1 = fa.flash_attn(q8, k8, v8, causal, descale=ds)
+            ref, _ = orc.naive_attention_f64(*deq, causal=causal)
+            for o in (o0, o1):
+                rel = np.linalg.norm(o.float().cpu().numpy() - ref) / np.linalg.norm(ref)
+                assert rel <= 5e-2
+            assert (o0.float() - o1.float()).abs().max() <= 2 ** -6
+    finally:
+        fa_mod._lib_handle = default
