@@ -145,6 +145,16 @@ __device__ __forceinline__ u32x2 lds_read_b64(unsigned addr) {
 __device__ __forceinline__ f32x4 mfma16_fp8(u32x2 a, u32x2 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bitcast<long>(a), bitcast<long>(b), c, 0, 0, 0);
 }
+// The same product over the whole head_dim in ONE instruction: v_mfma_scale_f32_16x16x128_f8f6f4 with fp8 A and B and unit
+// block scales (E8M0 127), twice the K = 32 form's rate.  Its k index is only summed over, so any (lane group, byte) ->
+// k map is right as long as both operands use the same one: the four 8-byte k-step fragments of the K = 32 form,
+// concatenated, are such a map (tools/probes/mfma_f8f6f4_probe.cpp checks the row / column lanes and the unit scales).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x4 mfma16_fp8_k128(const u32x2 (&a)[4], const u32x2 (&b)[4], f32x4 c) {
+    const i32x8 av = {(int)a[0][0], (int)a[0][1], (int)a[1][0], (int)a[1][1], (int)a[2][0], (int)a[2][1], (int)a[3][0], (int)a[3][1]};
+    const i32x8 bv = {(int)b[0][0], (int)b[0][1], (int)b[1][0], (int)b[1][1], (int)b[2][0], (int)b[2][1], (int)b[3][0], (int)b[3][1]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
 __device__ __forceinline__ void lds_write_b128(unsigned addr, u32x4 v) {
     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(addr) = v;
 }

@@ -273,6 +273,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         constexpr int par = decltype(par_c)::value, kt = decltype(kt_c)::value;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) s_acc[par][kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if !defined(FA_FP8_K32)
+        if constexpr (QK8) {           // one MX-scaled fp8 MFMA (unit scales) covers the whole head_dim
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) s_acc[par][kt][qt] = mfma16_fp8_k128(kf8, qf8[qt], s_acc[par][kt][qt]);
+            return;
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -304,6 +311,17 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
 #if !defined(FA_NO_SGB)
             if constexpr (DO_S && DO_SM && DO_PV) {
                 constexpr int NRD = decltype(nrd_c)::value, NV = decltype(nvalu_c)::value;
+#if !defined(FA_FP8_K32)
+                if constexpr (QK8 && NRD == 4) {      // an S region of the fp8 kernel: two K = 128 MFMAs
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x402, 4 * NV, 0);
+                    }
+                    return;
+                }
+#endif
 #if FA_SGB_VARIANT == 2
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {

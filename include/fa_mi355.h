@@ -86,7 +86,7 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 
 /*
  * fp8 (OCP e4m3fn) Q/K/V, bf16 O.  head_dim > 64: Q and K are consumed as fp8 by the score MFMAs
- * (v_mfma_f32_16x16x32_fp8_fp8); V is converted (exactly) to bf16 into the caller-provided device workspace by a HIP
+ * (v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: the whole head_dim per instruction); V is converted (exactly) to bf16 into the caller-provided device workspace by a HIP
  * pre-pass, because P V runs on bf16 MFMAs with P from the fp32 softmax.  head_dim <= 64: all three tensors are
  * converted and the bf16 kernel runs.  The q,k dequantisation scales are folded into the softmax scale, the v scale
  * into the output.  No reference counterpart (the reference is fp16 only); BASELINE.json config 5.
