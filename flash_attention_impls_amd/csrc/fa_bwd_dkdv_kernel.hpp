@@ -32,7 +32,14 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     constexpr int NW = 8;
     constexpr int XB = 128;                    // keys per workgroup (4 wave pairs x 32)
     constexpr int KS = D / 32, DT = D / 16, ROWB = D * 2, TILE = kBN * ROWB, PIECE = 1024;
-    constexpr int CPT = TILE / PIECE / NW;     // DMA pieces per wave, tile and operand
+    // staging duty goes to the four gradient waves only (macro FA_BWD_DMA_ALL: all eight): the score waves are the
+    // pole of every step and a DMA piece costs its issuer about 100 cycles
+#if defined(FA_BWD_DMA_ALL)
+    constexpr int NDMA = NW;
+#else
+    constexpr int NDMA = NW / 2;
+#endif
+    constexpr int CPT = TILE / PIECE / NDMA;   // DMA pieces per staging wave, tile and operand
     constexpr int NS = kDkdvStages;
     constexpr int Y2BASE = NS * TILE;
     constexpr int STBASE = 2 * NS * TILE;      // NS x 1 KiB of row statistics
@@ -88,9 +95,11 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const u32x4 ry1 = make_rsrc(y1h, y1_bytes);
     const u32x4 ry2 = make_rsrc(y2h, y2_bytes);
     unsigned g_y1[CPT], g_y2[CPT];
+    const int dwave = (NDMA == NW) ? wave : (wave & 3);          // staging index of this wave (gradient waves: 0..3)
+    const bool stager = (NDMA == NW) || role == 1;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-        const int byte = (wave * CPT + i) * PIECE + lane * 16;
+        const int byte = (dwave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
         const bool live = bwd_swz<D>(row, chp) * 8 < p.dv;       // chunks past the valid head_dim: out of the descriptor -> zeros
         g_y1[i] = live ? (unsigned)(row * p.y1_ss * 2 + bwd_swz<D>(row, chp) * 16) : 0x80000000u;
@@ -98,13 +107,14 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     }
     const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
     const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
-    const unsigned piece_base = lds_base + wave * CPT * PIECE;
+    const unsigned piece_base = lds_base + dwave * CPT * PIECE;
     const u32x4 rst = make_rsrc(p.stats, (unsigned)((long long)2 * p.bh * p.Spad * 4));
     unsigned g_st = 0x80000000u;           // lanes 0-15: LSE*log2e of the tile's rows, lanes 16-31: -delta, 16 bytes each
     if (lane < 32) g_st = (unsigned)((((long long)(lane >> 4) * p.bh + head) * p.Spad + (lane & 15) * 4) * 4);
     auto issue_tile = [&] __device__ (int j, auto stage_c) {
         constexpr int ST = decltype(stage_c)::value;
-        if (wave == 0) dma16(rst, __builtin_amdgcn_readfirstlane(lds_base + STBASE + ST * 1024), g_st + (unsigned)j * (kBN * 4));
+        if (!stager) return;
+        if (dwave == 0) dma16(rst, __builtin_amdgcn_readfirstlane(lds_base + STBASE + ST * 1024), g_st + (unsigned)j * (kBN * 4));
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
             dma16(ry1, __builtin_amdgcn_readfirstlane(piece_base + ST * TILE + i * PIECE), (unsigned)j * y1_tile_stride + g_y1[i]);
