@@ -216,3 +216,15 @@ def test_trace_ranges_are_optional_and_named_like_the_reference(monkeypatch):
     monkeypatch.setattr(torch.cuda.nvtx, "range_push", boom)
     with fmod._trace_range("FA2_BWD"):          # best effort: swallowed
         pass
+
+
+def test_header_is_plain_c():
+    """include/fa_mi355.h is the FFI contract: it must compile as C99 (no C++, no torch / HIP types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    hdr = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "fa_mi355.h")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    text = open(hdr).read()
+    assert "torch" not in text and "hipStream_t stream" not in text and "#include <hip" not in text
