@@ -51,20 +51,20 @@ int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
-// head_dim 128: kernel on 16x16x32 MFMA tiles (fa_fwd_kernel16.hpp)
-template <class T, bool CAUSAL>
+// kernel on 16x16x32 MFMA tiles (fa_fwd_kernel16.hpp), compiled head_dim D = 128 or 64
+template <class T, bool CAUSAL, int D>
 int launch16(const fa::FwdParams& p, int grid, hipStream_t stream)
 {
-    constexpr int lds = fa::lds_bytes<128>();
+    constexpr int lds = fa::lds_bytes<D>();
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel16<T, CAUSAL>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel16<T, CAUSAL, false, D>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((fa::fa_fwd_kernel16<T, CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((fa::fa_fwd_kernel16<T, CAUSAL, false, D>), dim3(grid), dim3(512), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
@@ -92,9 +92,15 @@ int launch16_qk8(const fa::FwdParams& p, int grid, hipStream_t stream)
 template <class T, int D>
 int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
 {
+    // default: the 16x16x32 kernel; -DFA_MFMA32 (and the FA_QB variants) select the 32x32x16 kernel of fa_fwd_kernel.hpp
 #if !defined(FA_MFMA32)
-    if constexpr (D == 128 && kQB == 1)
-        return causal ? launch16<T, true>(p, grid, s) : launch16<T, false>(p, grid, s);
+    if constexpr (kQB == 1) {
+        // head_dim 64: the 16x16 kernel fits two workgroups per CU (128 VGPRs, 64 KiB of LDS: +11-12 % at cfg3's
+        // batch and sequence); launches that do not fill the chip twice (cfg2: 128 workgroups) are latency-bound and
+        // 5 % faster on the 32x32 kernel
+        if (D == 128 || grid > 512)
+            return causal ? launch16<T, true, D>(p, grid, s) : launch16<T, false, D>(p, grid, s);
+    }
 #endif
     return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
 }

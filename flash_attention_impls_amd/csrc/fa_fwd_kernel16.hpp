@@ -33,13 +33,26 @@ namespace fa {
 // V tile swizzle for the 16x16x32 transposed reads: a 32-lane half reads 8 consecutive keys x 32 bytes;
 // XOR the 32-byte segment index with (key & 7) so they fill one 256-byte bank row.
 __device__ __forceinline__ int v_swz16(int row, int ch) { return ch ^ ((row & 7) << 1); }
+// head_dim 64 (128-byte rows, two per 256-byte bank row): one swizzle serves the K row reads and the V transposed
+// reads of the 16x16x32 maps (tools/lds_bank_sim.py, the image the backward kernels use)
+__device__ __forceinline__ int swz16_d64(int row, int ch) { return ch ^ (((row >> 1) & 3) << 1); }
+template <int D> __device__ __forceinline__ int k_swz16(int row, int ch) {
+    if constexpr (D == 128) return k_swz<128>(row, ch);
+    else return swz16_d64(row, ch);
+}
+template <int D> __device__ __forceinline__ int v_swz16d(int row, int ch) {
+    if constexpr (D == 128) return v_swz16(row, ch);
+    else return swz16_d64(row, ch);
+}
 
 // QK8: Q and K are fp8 (OCP e4m3) tensors (element strides = byte strides) and S^T = K Q^T runs on fp8 MFMAs; V (and
 // the P V product, O) stay 16-bit of type T.  The K tile then takes the first half of its ring stage (128-byte rows).
-template <class T, bool CAUSAL, bool QK8 = false>
-__global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
+template <class T, bool CAUSAL, bool QK8 = false, int DD = 128>
+__global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const FwdParams p)
 {
-    constexpr int D = 128;
+    constexpr int D = DD;                      // compiled head_dim: 128 or 64
+    static_assert(D == 128 || (D == 64 && !QK8), "head_dim 64 has no fp8 Q/K variant");
+    constexpr int NG = D / 64;                 // groups of four head_dim tiles in the P V product
     constexpr int NWAVES = 8;
     constexpr int QKB = QK8 ? 1 : 2;           // bytes per Q / K element
     constexpr int KROWB = D * QKB;             // bytes per K row in LDS
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         const int byte = (wave * CPT + i) * PIECE + lane * 16;
         const int row = byte / ROWB, chp = (byte % ROWB) / 16;
         // (chunks past the valid head_dim: an offset no tile index brings back into the descriptor -> zeros)
-        g_voff[i] = (v_swz16(row, chp) * 8 < p.dv) ? (unsigned)(row * p.v_ss * 2 + v_swz16(row, chp) * 16) : 0x80000000u;
+        g_voff[i] = (v_swz16d<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.v_ss * 2 + v_swz16d<D>(row, chp) * 16) : 0x80000000u;
     }
 #pragma unroll
     for (int i = 0; i < CPTK; ++i) {
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
             const int lc = chp ^ ((row >> 1) & 7);
             g_koff[i] = (lc * 16 < p.dv) ? (unsigned)(row * p.k_ss + lc * 16) : 0x80000000u;
         } else {
-            g_koff[i] = (k_swz<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.k_ss * 2 + k_swz<D>(row, chp) * 16) : 0x80000000u;
+            g_koff[i] = (k_swz16<D>(row, chp) * 8 < p.dv) ? (unsigned)(row * p.k_ss * 2 + k_swz16<D>(row, chp) * 16) : 0x80000000u;
         }
     }
     const unsigned k_tile_stride = (unsigned)(kBN * p.k_ss * QKB);
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
         ka[ks] = QK8 ? lds_base + li * KROWB + ((4 * ks + lg) ^ (((li >> 1) & 7) << 1)) * 8      // 8-byte granule 4 ks + lg of the row
-                     : lds_base + li * ROWB + k_swz<D>(li, 4 * ks + lg) * 16;
+                     : lds_base + li * ROWB + k_swz16<D>(li, 4 * ks + lg) * 16;
     // V^T fragment of head_dim tile dt: lane 4q+pp of a 16-lane group supplies key row 4 lg + q, head_dim
     // columns 16 dt + 4 pp .. +3 (8 bytes); second read 16 keys further down.
     unsigned va[DT];
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         const int row = 4 * lg + qq;                       // + 16 a + 32 half: multiples of 16, swizzle-neutral
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-            va[dt] = lds_base + VBASE + row * ROWB + v_swz16(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+            va[dt] = lds_base + VBASE + row * ROWB + v_swz16d<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
     }
 
     // fragment registers: one group of 4 K fragments, one group of 4 V^T fragments (re-read one group ahead)
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DO_PV) {
             mfma_pv(P_PV{}, IC<0>{});
-            read_vgroup(SV{}, IC<HALF>{}, IC<1>{});
+            if constexpr (NG == 2) read_vgroup(SV{}, IC<HALF>{}, IC<1>{});
         }
         if constexpr (DO_SM) {
             if constexpr (FIRST) sm_set_reference(mask_c, P_SM{}, key0);
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
         hint(IC<4>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 2: PV, head_dim tiles 4..7 | slice (kt 1, qt 0)
-        if constexpr (DO_PV) mfma_pv(P_PV{}, IC<1>{});
+        if constexpr (DO_PV && NG == 2) mfma_pv(P_PV{}, IC<1>{});
         typedef IC<(ST < 0 ? -1 : (HALF == 1 ? ((ST + 1) & 3) : ST))> SKn;      // stages the next block reads
         typedef IC<(ST < 0 ? -1 : (HALF == 1 ? ST : ((ST + 3) & 3)))> SVn;
         if constexpr (HALF == 1 && ST < 0) advance(dk, dv);
@@ -509,13 +522,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel16(const FwdParams p)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             ka2[ks] = QK8 ? lds_base + KO + li * KROWB + ((4 * ks + lg) ^ (((li >> 1) & 7) << 1)) * 8
-                          : lds_base + KO + li * ROWB + k_swz<D>(li, 4 * ks + lg) * 16;
+                          : lds_base + KO + li * ROWB + k_swz16<D>(li, 4 * ks + lg) * 16;
         {
             const int qq = li >> 2, pp = li & 3;
             const int row = 4 * lg + qq;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
-                va2[dt] = lds_base + VO + row * ROWB + v_swz16(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
+                va2[dt] = lds_base + VO + row * ROWB + v_swz16d<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
         }
         auto dma2 = [&](int jj) {
             const unsigned st = (jj & 1) * TILE;
