@@ -117,6 +117,19 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
            int dtype, int causal, float softmax_scale,
            void* workspace, size_t workspace_bytes, void* stream)
 {
+    return fa_bwd_gqa(q, k, v, o, d_o, lse, dq, dk, dv, B, H, H, S, D, q_strides, k_strides, v_strides, o_strides, do_strides,
+                      dq_strides, dk_strides, dv_strides, dtype, causal, softmax_scale, workspace, workspace_bytes, stream);
+}
+
+int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+               void* dq, void* dk, void* dv,
+               int B, int H, int H_kv, int S, int D,
+               const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+               const int64_t* o_strides, const int64_t* do_strides,
+               const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
+               int dtype, int causal, float softmax_scale,
+               void* workspace, size_t workspace_bytes, void* stream)
+{
     g_err[0] = 0;
     if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16)
         return fail(FA_ERR_BAD_DTYPE, "backward supports bf16 and fp16 (dtype code %d)", dtype);
@@ -125,6 +138,11 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     const bool big = D > 64;                 // head_dim-128 kernels, otherwise the head_dim-64 ones (columns past D read as zeros)
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;
+    if (H_kv <= 0 || H % H_kv != 0)
+        return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
+#if defined(FA_BWD_DKDV_SINGLE)
+    if (H_kv != H) return fail(FA_ERR_BAD_SHAPE, "this build's dK/dV kernel serves equal head counts only");
+#endif
     if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !workspace)
         return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
     if (workspace_bytes < fa_bwd_workspace_bytes(B, H, S))
@@ -134,8 +152,9 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     const int64_t* given[8] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
     const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
     long long max_ss = 0;
+    const int heads[8] = {H, H_kv, H_kv, H, H, H, H_kv, H_kv};
     for (int i = 0; i < 8; ++i) {
-        if (!set_strides(given[i], H, S, D, st[i][0], st[i][1], st[i][2]))
+        if (!set_strides(given[i], heads[i], S, D, st[i][0], st[i][1], st[i][2]))
             return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
         for (int c = 0; c < 3; ++c)
             if ((st[i][c] * 2) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "stride %lld elements is not 16-byte aligned", st[i][c]);
@@ -167,6 +186,7 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     memset(&pq, 0, sizeof(pq));
     pq.stats = stats;
     pq.B = B; pq.H = H; pq.S = S; pq.dv = D; pq.Spad = Spad; pq.bh = B * H;
+    pq.G = H / H_kv;
     pq.scale = scale;
     pq.scale_log2 = scale * 1.4426950408889634f;
     fa::BwdParams pk = pq;
@@ -178,7 +198,8 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
     pq.y2_sb = st[2][0]; pq.y2_sh = st[2][1]; pq.y2_ss = st[2][2];
     pq.o1_sb = st[5][0]; pq.o1_sh = st[5][1]; pq.o1_ss = st[5][2];
     pq.nxb = (S + 32 * fa::bwd_waves<0>() - 1) / (32 * fa::bwd_waves<0>());
-    // MODE 1 (dK, dV): stationary K, V; streamed Q, dO
+    // dK, dV: stationary K, V (the grid runs over the key/value heads); streamed Q, dO of the group's query heads
+    pk.H = H_kv; pk.bh = B * H_kv;
     pk.x1 = k; pk.x2 = v; pk.y1 = q; pk.y2 = d_o; pk.out1 = dk; pk.out2 = dv;
     pk.x1_sb = st[1][0]; pk.x1_sh = st[1][1]; pk.x1_ss = st[1][2];
     pk.x2_sb = st[2][0]; pk.x2_sh = st[2][1]; pk.x2_ss = st[2][2];
@@ -190,7 +211,7 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
 
     // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp)
     const int grid_q = bwd_grid((long long)B * H, causal != 0 ? (pq.nxb + 1) / 2 : pq.nxb);
-    const int grid_k = bwd_grid((long long)B * H, pk.nxb);
+    const int grid_k = bwd_grid((long long)B * H_kv, pk.nxb);
     if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     const bool c = causal != 0;
     if (dtype == FA_DTYPE_BF16)

@@ -73,8 +73,11 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     using elem_t = unsigned short;
     const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh;     // K
     const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + h * p.x2_sh;     // V
-    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + h * p.y1_sh;     // Q
-    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + h * p.y2_sh;     // dO
+    // Q and dO of the G query heads that share this key/value head (h G .. h G + G-1) are streamed one head after the other
+    const int headq0 = head * p.G;                                                             // first of them, counted over all batches
+    const int bhq = p.bh * p.G;                                                                // query heads in all
+    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + (h * p.G) * p.y1_sh;   // Q
+    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + (h * p.G) * p.y2_sh;   // dO
 
     // ---- streamed range of the workgroup (tiles) and of this pair (blocks)
     const int nty = (S + kBN - 1) / kBN;
@@ -92,8 +95,14 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     // ---- staging by LDS-DMA (as fa_bwd_kernel.hpp), 8 waves
     const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + p.dv) * 2);
     const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + p.dv) * 2);
-    const u32x4 ry1 = make_rsrc(y1h, y1_bytes);
-    const u32x4 ry2 = make_rsrc(y2h, y2_bytes);
+    u32x4 ry1, ry2;                        // descriptors of the current query head's Q and dO
+    unsigned g_st = 0x80000000u;           // lanes 0-15: LSE*log2e of the tile's rows, lanes 16-31: -delta, 16 bytes each
+    if (lane < 32) g_st = (unsigned)((((long long)(lane >> 4) * bhq + headq0) * p.Spad + (lane & 15) * 4) * 4);
+    auto next_query_head = [&] __device__ () {          // (lanes >= 32 stay far outside the statistics descriptor)
+        y1h += p.y1_sh;
+        y2h += p.y2_sh;
+        g_st += (unsigned)p.Spad * 4;
+    };
     unsigned g_y1[CPT], g_y2[CPT];
     const int dwave = (NDMA == NW) ? wave : (wave & 3);          // staging index of this wave (gradient waves: 0..3)
     const bool stager = (NDMA == NW) || role == 1;
@@ -108,9 +117,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
     const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
     const unsigned piece_base = lds_base + dwave * CPT * PIECE;
-    const u32x4 rst = make_rsrc(p.stats, (unsigned)((long long)2 * p.bh * p.Spad * 4));
-    unsigned g_st = 0x80000000u;           // lanes 0-15: LSE*log2e of the tile's rows, lanes 16-31: -delta, 16 bytes each
-    if (lane < 32) g_st = (unsigned)((((long long)(lane >> 4) * p.bh + head) * p.Spad + (lane & 15) * 4) * 4);
+    const u32x4 rst = make_rsrc(p.stats, (unsigned)((long long)2 * bhq * p.Spad * 4));
     auto issue_tile = [&] __device__ (int j, auto stage_c) {
         constexpr int ST = decltype(stage_c)::value;
         if (!stager) return;
@@ -165,8 +172,17 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     // one trip = one turn of the ring (6 blocks); step i = 2 j_end only drains the gradient waves.  The two roles run
     // separate loops (separate register sets) with the same sequence of barriers: one in the prologue (tile j_begin
     // published; the score waves compute their first scores behind it), then one per step.
+    // Outer loop: the G query heads of the group, each a complete pass of the pipeline (ring and mailbox start over
+    // behind a barrier; the gradient accumulators carry on).
     auto for_all_steps = [&] __device__ (auto&& prologue, auto&& body) {
         if (j_begin >= j_end) return;
+      for (int g = 0; g < p.G; ++g) {
+        if (g > 0) {
+            __syncthreads();                                      // the previous head's last blocks have left the ring
+            next_query_head();
+        }
+        ry1 = make_rsrc(y1h, y1_bytes);
+        ry2 = make_rsrc(y2h, y2_bytes);
         issue_tile(j_begin, IC<0>{});
         issue_tile(j_begin + 1, IC<1>{});
         dma_wait<OPS>();                                          // tile j_begin has landed (tile j_begin + 1 stays in flight)
@@ -180,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             if (i + 4 <= 2 * j_end) body(IC<2>{}, IC<0>{}, i + 4);
             if (i + 5 <= 2 * j_end) body(IC<2>{}, IC<1>{}, i + 5);
         }
+      }
     };
 
     if (role == 0) {

@@ -42,7 +42,11 @@ struct BwdParams {
     const void* y1; const void* y2;     // streamed operands:   MODE 0: K, V  ; MODE 1: Q, dO
     void* out1; void* out2;             // MODE 0: dQ, unused ; MODE 1: dK, dV
     const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then -delta (0 past S)
-    int B, H, S;
+    int B, H, S;                        // H: heads of the stationary operands (= of the grid)
+    int G;                              // grouped-query attention, query heads per key/value head (1 = equal head counts).
+                                        // MODE 0: H query heads, the streamed K / V have H / G heads (head h reads h / G);
+                                        // dK/dV kernel: H key/value heads, G query heads (h G .. h G + G-1) are streamed
+                                        // one after the other into the same accumulators; stats cover B * H * G heads
     int dv;                             // valid head_dim (multiple of 16, <= the compiled D): columns past it read as zeros, are not stored
     int Spad;                           // S rounded up to a multiple of 64
     int bh;                             // B*H
@@ -177,8 +181,11 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     using elem_t = unsigned short;
     const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh;
     const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + h * p.x2_sh;
-    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + h * p.y1_sh;
-    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + h * p.y2_sh;
+    // MODE 0: the key/value head of a query head (grouped-query attention); MODE 1 (the single-wave dK/dV variant) is
+    // launched for equal head counts only
+    const int hy = MODE == 0 ? h / p.G : h;
+    const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + hy * p.y1_sh;
+    const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + hy * p.y2_sh;
 
     // ---- streamed range of the workgroup (64-row tiles) and of this wave (32-row blocks)
     const int nty = (S + kBN - 1) / kBN;

@@ -178,6 +178,17 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            int dtype, int causal, float softmax_scale,
            const float* descale, void* stream)
 {
+    return fa_fwd_gqa(q, k, v, o, lse, B, H, H, S, D, q_strides, k_strides, v_strides, o_strides,
+                      dtype, causal, softmax_scale, descale, stream);
+}
+
+int fa_fwd_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
+               int B, int H, int H_kv, int S, int D,
+               const int64_t* q_strides, const int64_t* k_strides,
+               const int64_t* v_strides, const int64_t* o_strides,
+               int dtype, int causal, float softmax_scale,
+               const float* descale, void* stream)
+{
     g_err[0] = 0;
     if (dtype == FA_DTYPE_FP8_E4M3)
         return fail(FA_ERR_BAD_DTYPE, "fp8 inputs need a workspace: call fa_fwd_fp8");
@@ -187,18 +198,21 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
         return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 128)", D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;        // empty problem: nothing to do
+    if (H_kv <= 0 || H % H_kv != 0)
+        return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
     if (!q || !k || !v || !o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
 
     fa::FwdParams p;
     memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
     p.B = B; p.H = H; p.S = S;
+    p.G = H / H_kv;
     p.dv = D;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.bh = B * H;
     if (!set_strides(q_strides, H, S, D, p.q_sb, p.q_sh, p.q_ss) ||
-        !set_strides(k_strides, H, S, D, p.k_sb, p.k_sh, p.k_ss) ||
-        !set_strides(v_strides, H, S, D, p.v_sb, p.v_sh, p.v_ss) ||
+        !set_strides(k_strides, H_kv, S, D, p.k_sb, p.k_sh, p.k_ss) ||
+        !set_strides(v_strides, H_kv, S, D, p.v_sb, p.v_sh, p.v_ss) ||
         !set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss))
         return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
     const long long esz = 2;
@@ -250,27 +264,24 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
                int causal, float softmax_scale, const float* descale,
                void* workspace, size_t workspace_bytes, void* stream)
 {
+    return fa_fwd_fp8_gqa(q, k, v, o, lse, B, H, H, S, D, q_strides, k_strides, v_strides, o_strides,
+                          causal, softmax_scale, descale, workspace, workspace_bytes, stream);
+}
+
+int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
+                   int B, int H, int H_kv, int S, int D,
+                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                   int causal, float softmax_scale, const float* descale,
+                   void* workspace, size_t workspace_bytes, void* stream)
+{
     g_err[0] = 0;
     if (!fa_supported(FA_DTYPE_FP8_E4M3, D))
         return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 128)", D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;
+    if (H_kv <= 0 || H % H_kv != 0)
+        return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
     if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
-    if (workspace_bytes < fa_fp8_workspace_bytes(B, H, S, D))
-        return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, fa_fp8_workspace_bytes(B, H, S, D));
-    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
-    const void* src[3] = {q, k, v};
-    const int64_t* strd[3] = {q_strides, k_strides, v_strides};
-    const long long rows = (long long)B * H * S;
-    const size_t one = (size_t)rows * D * 2;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    long long st[3][3];
-    for (int t = 0; t < 3; ++t) {
-        if (!set_strides(strd[t], H, S, D, st[t][0], st[t][1], st[t][2])) return fail(FA_ERR_BAD_STRIDE, "bad strides");
-        if (st[t][0] % 16 || st[t][1] % 16 || st[t][2] % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
-            return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
-    }
-    if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the fp8 pre-pass");
 #if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
     const bool native_qk = false;
 #else
@@ -278,32 +289,50 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
     // LDS-DMA and LDS reads); only V is converted, because P V runs on bf16 MFMAs with P from the fp32 softmax
     const bool native_qk = D > 64;
 #endif
+    const int heads[3] = {H, H_kv, H_kv};
+    const size_t one_q = (size_t)B * H * S * D * 2, one_kv = (size_t)B * H_kv * S * D * 2;   // bf16 copies
+    const size_t need = native_qk ? one_kv : one_q + 2 * one_kv;
+    if (workspace_bytes < need)
+        return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
+    const void* src[3] = {q, k, v};
+    const int64_t* strd[3] = {q_strides, k_strides, v_strides};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    long long st[3][3];
+    for (int t = 0; t < 3; ++t) {
+        if (!set_strides(strd[t], heads[t], S, D, st[t][0], st[t][1], st[t][2])) return fail(FA_ERR_BAD_STRIDE, "bad strides");
+        if (st[t][0] % 16 || st[t][1] % 16 || st[t][2] % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
+            return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
+    }
+    if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the fp8 pre-pass");
     char* w = static_cast<char*>(workspace);
-    const int first = native_qk ? 2 : 0;                // the workspace holds the converted tensors back to back
-    for (int t = first; t < 3; ++t) {
+    char* wt[3] = {w, w + one_q, w + one_q + one_kv};   // the workspace holds the converted tensors back to back
+    if (native_qk) wt[2] = w;
+    for (int t = native_qk ? 2 : 0; t < 3; ++t) {
         const int per_slice = S * (D / 16);
         const int bx = std::max(1, std::min((per_slice + 255) / 256, 64));
-        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(bx, B * H), dim3(256), 0, s,
+        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(bx, B * heads[t]), dim3(256), 0, s,
                            reinterpret_cast<const unsigned char*>(src[t]),
-                           reinterpret_cast<unsigned short*>(w + (t - first) * one),
-                           D, H, S, st[t][0], st[t][1], st[t][2]);
+                           reinterpret_cast<unsigned short*>(wt[t]),
+                           D, heads[t], S, st[t][0], st[t][1], st[t][2]);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fp8 conversion launch failed: %s", hipGetErrorString(e));
     }
     if (!native_qk)
-        return fa_fwd(w, w + one, w + 2 * one, o, lse, B, H, S, D, nullptr, nullptr, nullptr, o_strides,
-                      FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
+        return fa_fwd_gqa(wt[0], wt[1], wt[2], o, lse, B, H, H_kv, S, D, nullptr, nullptr, nullptr, o_strides,
+                          FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
 
     if (!o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
     fa::FwdParams p;
     memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = w; p.o = o; p.lse = lse;
     p.B = B; p.H = H; p.S = S; p.dv = D;
+    p.G = H / H_kv;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.bh = B * H;
     p.q_sb = st[0][0]; p.q_sh = st[0][1]; p.q_ss = st[0][2];
     p.k_sb = st[1][0]; p.k_sh = st[1][1]; p.k_ss = st[1][2];
-    p.v_ss = D; p.v_sh = (long long)S * D; p.v_sb = (long long)H * S * D;
+    p.v_ss = D; p.v_sh = (long long)S * D; p.v_sb = (long long)H_kv * S * D;
     if (!set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss)) return fail(FA_ERR_BAD_STRIDE, "bad output strides");
     if ((p.o_sb * 2) % 16 || (p.o_sh * 2) % 16 || (p.o_ss * 2) % 16 || reinterpret_cast<uintptr_t>(o) % 16)
         return fail(FA_ERR_BAD_STRIDE, "output rows must be 16-byte aligned");

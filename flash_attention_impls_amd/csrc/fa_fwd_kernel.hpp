@@ -46,6 +46,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct FwdParams {
     const void* q; const void* k; const void* v; void* o; float* lse;
     int B, H, S;
+    int G;                   // query heads per key/value head (1 = the reference's case): K, V have H / G heads
     int dv;                  // valid head_dim (a multiple of 16, <= the kernel's compiled D): columns dv .. D-1 of every
                              // Q / K / V row are read as zeros (buffer offsets pushed out of range) and not stored in O
     int nqb;                 // ceil(S / 256)
@@ -270,8 +271,8 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
 
     using elem_t = unsigned short;
     const elem_t* qh = reinterpret_cast<const elem_t*>(p.q) + b * p.q_sb + h * p.q_sh;
-    const elem_t* kh = reinterpret_cast<const elem_t*>(p.k) + b * p.k_sb + h * p.k_sh;
-    const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + h * p.v_sh;
+    const elem_t* kh = reinterpret_cast<const elem_t*>(p.k) + b * p.k_sb + (h / p.G) * p.k_sh;
+    const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + (h / p.G) * p.v_sh;
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
     const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * 2);

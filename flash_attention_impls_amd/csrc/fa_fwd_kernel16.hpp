@@ -86,8 +86,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     using elem_t = unsigned short;
     const char* qh = reinterpret_cast<const char*>(p.q) + (b * p.q_sb + h * p.q_sh) * QKB;
-    const char* kh = reinterpret_cast<const char*>(p.k) + (b * p.k_sb + h * p.k_sh) * QKB;
-    const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + h * p.v_sh;
+    const int hk = h / p.G;                    // grouped-query attention: G query heads share a key/value head
+    const char* kh = reinterpret_cast<const char*>(p.k) + (b * p.k_sb + hk * p.k_sh) * QKB;
+    const elem_t* vh = reinterpret_cast<const elem_t*>(p.v) + b * p.v_sb + hk * p.v_sh;
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
     const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * QKB);

@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             "fa_fwd_launch_info", "fa_fwd_fp8", "fa_fp8_workspace_bytes"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
-    assert lib.fa_version() == 110
+    assert lib.fa_version() == 120
     assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
 
 
@@ -228,3 +228,26 @@ def test_header_is_plain_c():
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
     text = open(hdr).read()
     assert "torch" not in text and "hipStream_t stream" not in text and "#include <hip" not in text
+
+
+def test_grouped_query_entry_points_validate_without_gpu():
+    """fa_*_gqa: H must be a multiple of H_kv (checked before any launch); the host check accepts such shapes."""
+    lib = fa.load_library()
+    null = None
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.fa_fwd_gqa(p, p, p, p, null, 1, 6, 4, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == -3
+    assert b"H_kv" in lib.fa_last_error()
+    assert lib.fa_fwd_gqa(p, p, p, p, null, 1, 6, 0, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == -3
+    assert lib.fa_fwd_fp8_gqa(p, p, p, p, null, 1, 6, 4, 8, 128, null, null, null, null, 0, 0.0, null, p, 1 << 20, null) == -3
+    n = lib.fa_bwd_workspace_bytes(1, 6, 8)
+    assert lib.fa_bwd_gqa(*([p] * 9), 1, 6, 4, 8, 128, *([null] * 8), 0, 0, 0.0, p, n, null) == -3
+    assert lib.fa_fwd_gqa(null, null, null, null, null, 0, 6, 2, 8, 128, null, null, null, null, 0, 0, 0.0, null, null) == 0
+    # host side: k, v may have a head count that divides q's; the "no CPU path" rule comes after the shape rules
+    q, k = torch.zeros(1, 6, 8, 64), torch.zeros(1, 2, 8, 64)
+    with pytest.raises(fa.FlashAttnArgumentError, match="no CPU path"):
+        fa.check_args(q, k, k)
+    with pytest.raises(fa.FlashAttnArgumentError, match="identical shapes"):
+        fa.check_args(q, torch.zeros(1, 4, 8, 64), torch.zeros(1, 4, 8, 64))
+    with pytest.raises(fa.FlashAttnArgumentError, match="identical shapes"):
+        fa.check_args(q, k, torch.zeros(1, 3, 8, 64))
