@@ -117,13 +117,13 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
            int dtype, int causal, float softmax_scale,
            void* workspace, size_t workspace_bytes, void* stream)
 {
-    return fa_bwd_gqa(q, k, v, o, d_o, lse, dq, dk, dv, B, H, H, S, D, q_strides, k_strides, v_strides, o_strides, do_strides,
+    return fa_bwd_ex(q, k, v, o, d_o, lse, dq, dk, dv, B, H, H, S, S, D, q_strides, k_strides, v_strides, o_strides, do_strides,
                       dq_strides, dk_strides, dv_strides, dtype, causal, softmax_scale, workspace, workspace_bytes, stream);
 }
 
-int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                void* dq, void* dk, void* dv,
-               int B, int H, int H_kv, int S, int D,
+               int B, int H, int H_kv, int S, int S_k, int D,
                const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                const int64_t* o_strides, const int64_t* do_strides,
                const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
@@ -140,8 +140,11 @@ int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const
     if (B == 0 || H == 0 || S == 0) return FA_OK;
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
+    if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
+    if (causal && S_k < S)
+        return fail(FA_ERR_BAD_SHAPE, "causal mask (bottom-right aligned) needs S_k >= S_q; got S_q=%d, S_k=%d", S, S_k);
 #if defined(FA_BWD_DKDV_SINGLE)
-    if (H_kv != H) return fail(FA_ERR_BAD_SHAPE, "this build's dK/dV kernel serves equal head counts only");
+    if (H_kv != H || S_k != S) return fail(FA_ERR_BAD_SHAPE, "this build's dK/dV kernel serves equal head counts and lengths only");
 #endif
     if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !workspace)
         return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
@@ -153,8 +156,9 @@ int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const
     const void* ptrs[8] = {q, k, v, o, d_o, dq, dk, dv};
     long long max_ss = 0;
     const int heads[8] = {H, H_kv, H_kv, H, H, H, H_kv, H_kv};
+    const int rows[8] = {S, S_k, S_k, S, S, S, S_k, S_k};
     for (int i = 0; i < 8; ++i) {
-        if (!set_strides(given[i], heads[i], S, D, st[i][0], st[i][1], st[i][2]))
+        if (!set_strides(given[i], heads[i], rows[i], D, st[i][0], st[i][1], st[i][2]))
             return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
         for (int c = 0; c < 3; ++c)
             if ((st[i][c] * 2) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "stride %lld elements is not 16-byte aligned", st[i][c]);
@@ -163,8 +167,8 @@ int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const
     }
     if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
     // 32-bit buffer offsets inside one (batch, head) slice, with room for two prefetched tiles
-    if (((long long)S + 4 * fa::kBN) * max_ss * 2 >= (1ll << 31))
-        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", S, max_ss);
+    if (((long long)std::max(S, S_k) + 4 * fa::kBN) * max_ss * 2 >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", std::max(S, S_k), max_ss);
     const int Spad = (S + fa::kBN - 1) / fa::kBN * fa::kBN;
     if ((long long)2 * B * H * Spad * 4 + 4 * fa::kBN * 4 >= (1ll << 31))
         return fail(FA_ERR_TOO_LARGE, "row statistics exceed 2 GiB (B*H*S = %lld)", (long long)B * H * S);
@@ -187,6 +191,8 @@ int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const
     pq.stats = stats;
     pq.B = B; pq.H = H; pq.S = S; pq.dv = D; pq.Spad = Spad; pq.bh = B * H;
     pq.G = H / H_kv;
+    pq.Sy = S_k;                        // dQ: queries stationary, keys streamed
+    pq.coff = S_k - S;
     pq.scale = scale;
     pq.scale_log2 = scale * 1.4426950408889634f;
     fa::BwdParams pk = pq;
@@ -200,6 +206,7 @@ int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const
     pq.nxb = (S + 32 * fa::bwd_waves<0>() - 1) / (32 * fa::bwd_waves<0>());
     // dK, dV: stationary K, V (the grid runs over the key/value heads); streamed Q, dO of the group's query heads
     pk.H = H_kv; pk.bh = B * H_kv;
+    pk.S = S_k; pk.Sy = S;
     pk.x1 = k; pk.x2 = v; pk.y1 = q; pk.y2 = d_o; pk.out1 = dk; pk.out2 = dv;
     pk.x1_sb = st[1][0]; pk.x1_sh = st[1][1]; pk.x1_ss = st[1][2];
     pk.x2_sb = st[2][0]; pk.x2_sh = st[2][1]; pk.x2_ss = st[2][2];
@@ -207,7 +214,7 @@ int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const
     pk.y2_sb = st[4][0]; pk.y2_sh = st[4][1]; pk.y2_ss = st[4][2];
     pk.o1_sb = st[6][0]; pk.o1_sh = st[6][1]; pk.o1_ss = st[6][2];
     pk.o2_sb = st[7][0]; pk.o2_sh = st[7][1]; pk.o2_ss = st[7][2];
-    pk.nxb = (S + 32 * fa::bwd_waves<1>() - 1) / (32 * fa::bwd_waves<1>());
+    pk.nxb = (S_k + 32 * fa::bwd_waves<1>() - 1) / (32 * fa::bwd_waves<1>());
 
     // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp)
     const int grid_q = bwd_grid((long long)B * H, causal != 0 ? (pq.nxb + 1) / 2 : pq.nxb);

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     if (head >= p.bh) return;
     const int b = head / p.H;
     const int h = head - b * p.H;
-    const int S = p.S;
+    const int S = p.S;                         // keys
+    const int Sy = p.Sy;                       // queries
+    const int coff = CAUSAL ? p.coff : 0;      // key <= query + coff
     const int x0 = xb * XB;
     const int x0w = x0 + pair * 32;            // first key of this wave pair
 
@@ -80,21 +82,23 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + (h * p.G) * p.y2_sh;   // dO
 
     // ---- streamed range of the workgroup (tiles) and of this pair (blocks)
-    const int nty = (S + kBN - 1) / kBN;
+    const int nty = (Sy + kBN - 1) / kBN;
     int j_begin = 0;
     const int j_end = nty;
-    int blk_begin_w = 0, blk_end_w = (S + 31) / 32;
-    int blk_mask = -1;                                    // the diagonal block
+    int blk_begin_w = 0, blk_end_w = (Sy + 31) / 32;
+    int blk_mask = 0, blk_mask_hi = -1;                   // the diagonal block(s): two when coff is not a multiple of 32
     if constexpr (CAUSAL) {
-        j_begin = min(nty, x0 / kBN);
-        blk_begin_w = x0w >> 5;                           // earlier blocks hold only queries < this pair's keys
-        blk_mask = x0w >> 5;
+        const int q_lo = x0w - coff;                      // first query that sees this pair's first key
+        j_begin = min(nty, max(0, x0 - coff) / kBN);
+        blk_begin_w = max(0, q_lo) >> 5;                  // earlier blocks hold only queries that see none of this pair's keys
+        blk_mask = blk_begin_w;
+        blk_mask_hi = (q_lo + 31 < 0) ? -1 : (q_lo + 31) >> 5;
     }
     if (x0w >= S) { blk_begin_w = 0; blk_end_w = 0; }     // no keys: staging duty only
 
     // ---- staging by LDS-DMA (as fa_bwd_kernel.hpp), 8 waves
-    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + p.dv) * 2);
-    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + p.dv) * 2);
+    const unsigned y1_bytes = (unsigned)(((long long)(Sy - 1) * p.y1_ss + p.dv) * 2);
+    const unsigned y2_bytes = (unsigned)(((long long)(Sy - 1) * p.y2_ss + p.dv) * 2);
     u32x4 ry1, ry2;                        // descriptors of the current query head's Q and dO
     unsigned g_st = 0x80000000u;           // lanes 0-15: LSE*log2e of the tile's rows, lanes 16-31: -delta, 16 bytes each
     if (lane < 32) g_st = (unsigned)((((long long)(lane >> 4) * bhq + headq0) * p.Spad + (lane & 15) * 4) * 4);
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             u32x4 pw[2], dsw[2];
 #pragma unroll
             for (int xt = 0; xt < 2; ++xt) {
-                const int xrow = x0w + 16 * xt + li;
+                const int xrow = x0w + 16 * xt + li - coff;
 #pragma unroll
                 for (int yt = 0; yt < 2; ++yt) {
                     float pv[4];
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     for (int e = 0; e < 4; ++e) {
                         pv[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[BLK][yt][xt][e], c, -lse_y[yt][e]));
                         if constexpr (MASK) {
-                            if (xrow > y0 + 16 * yt + 4 * lg + e) pv[e] = 0.f;          // key > query
+                            if (xrow > y0 + 16 * yt + 4 * lg + e) pv[e] = 0.f;          // key - coff > query
                         }
                     }
                     pw[xt][2 * yt] = T::pack2(pv[0], pv[1]);
@@ -302,7 +306,8 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     if constexpr (HALF == 0) scores(IC<ST>{}, IC<1>{});
                     else scores(IC<(ST + 1) % NS>{}, IC<0>{});
                 };
-                if (do_sc && do_sm && !(CAUSAL && i == blk_mask)) {          // steady state: one straight-line region
+                const bool diag = CAUSAL && i >= blk_mask && i <= blk_mask_hi;
+                if (do_sc && do_sm && !diag) {          // steady state: one straight-line region
                     __builtin_amdgcn_sched_barrier(0);       // (also keeps the compiler from folding this path into the guarded one)
                     next_scores();
                     softmax(std::false_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                 } else {
                     if (do_sc) next_scores();
                     if (do_sm) {
-                        if (CAUSAL && i == blk_mask) softmax(std::true_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
+                        if (diag) softmax(std::true_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
                         else softmax(std::false_type{}, IC<ST>{}, IC<HALF>{}, i * 32);
                     }
                 }

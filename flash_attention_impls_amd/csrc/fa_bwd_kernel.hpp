@@ -42,7 +42,9 @@ struct BwdParams {
     const void* y1; const void* y2;     // streamed operands:   MODE 0: K, V  ; MODE 1: Q, dO
     void* out1; void* out2;             // MODE 0: dQ, unused ; MODE 1: dK, dV
     const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then -delta (0 past S)
-    int B, H, S;                        // H: heads of the stationary operands (= of the grid)
+    int B, H, S;                        // H, S: heads and rows of the stationary operands (= of the grid)
+    int Sy;                             // rows of the streamed operands (MODE 0: keys, dK/dV kernel: queries)
+    int coff;                           // keys - queries: the causal mask is bottom-right aligned, key <= query + coff (>= 0)
     int G;                              // grouped-query attention, query heads per key/value head (1 = equal head counts).
                                         // MODE 0: H query heads, the streamed K / V have H / G heads (head h reads h / G);
                                         // dK/dV kernel: H key/value heads, G query heads (h G .. h G + G-1) are streamed
@@ -166,6 +168,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;
+    const int Sy = p.Sy;
+    const int coff = (CAUSAL && MODE == 0) ? p.coff : 0;      // (MODE 1 is launched for equal lengths only)
     const int n_pass = (PAIR && p.nxb - 1 - t != t) ? 2 : 1;
   for (int pass = 0; pass < n_pass; ++pass) {
     const int xb = PAIR ? (pass == 0 ? p.nxb - 1 - t : t) : t;
@@ -188,15 +192,15 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + hy * p.y2_sh;
 
     // ---- streamed range of the workgroup (64-row tiles) and of this wave (32-row blocks)
-    const int nty = (S + kBN - 1) / kBN;
+    const int nty = (Sy + kBN - 1) / kBN;
     int j_begin = 0, j_end = nty;
-    int blk_begin_w = 0, blk_end_w = (S + 31) / 32;      // blocks this wave computes on
+    int blk_begin_w = 0, blk_end_w = (Sy + 31) / 32;     // blocks this wave computes on
     int blk_mask_lo = 0x7fffffff, blk_mask_hi = -1;      // blocks in [lo, hi] need the causal mask
     if constexpr (CAUSAL) {
         if constexpr (MODE == 0) {                        // queries stationary, keys streamed: keys <= query
-            j_end = min(nty, (min(S, x0 + XB) + kBN - 1) / kBN);
-            blk_end_w = (x0w >= S) ? 0 : (min(S, x0w + 32) + 31) / 32;
-            blk_mask_lo = x0w >> 5;                       // first block containing a key > the wave's first query
+            j_end = min(nty, (min(Sy, min(S, x0 + XB) + coff) + kBN - 1) / kBN);
+            blk_end_w = (x0w >= S) ? 0 : (min(Sy, min(S, x0w + 32) + coff) + 31) / 32;
+            blk_mask_lo = (x0w + coff) >> 5;              // first block containing a key > the wave's first query (+ coff)
             blk_mask_hi = 0x7fffffff;
         } else {                                          // keys stationary, queries streamed: queries >= key
             j_begin = min(nty, x0 / kBN);
@@ -265,8 +269,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     }
 
     // ---- staging by LDS-DMA: piece (wave * CPT + i) of a tile, swizzle applied on the source address
-    const unsigned y1_bytes = (unsigned)(((long long)(S - 1) * p.y1_ss + p.dv) * 2);
-    const unsigned y2_bytes = (unsigned)(((long long)(S - 1) * p.y2_ss + p.dv) * 2);
+    const unsigned y1_bytes = (unsigned)(((long long)(Sy - 1) * p.y1_ss + p.dv) * 2);
+    const unsigned y2_bytes = (unsigned)(((long long)(Sy - 1) * p.y2_ss + p.dv) * 2);
     const u32x4 ry1 = make_rsrc(y1h, y1_bytes);
     const u32x4 ry2 = make_rsrc(y2h, y2_bytes);
     unsigned g_y1[CPT], g_y2[CPT];
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
                     float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(t1[PAR][yt][xt][e], c, -l2));
                     if constexpr (MASK) {
                         const int yrow = y0 + 16 * yt + 4 * lg + e;
-                        const bool dead = (MODE == 0) ? (yrow > xrow) : (xrow > yrow);     // key > query
+                        const bool dead = (MODE == 0) ? (yrow > xrow + coff) : (xrow > yrow);     // key > query (+ coff)
                         if (dead) pe = 0.f;
                     }
                     pv[e] = pe;

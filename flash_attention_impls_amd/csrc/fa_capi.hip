@@ -178,16 +178,16 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            int dtype, int causal, float softmax_scale,
            const float* descale, void* stream)
 {
-    return fa_fwd_gqa(q, k, v, o, lse, B, H, H, S, D, q_strides, k_strides, v_strides, o_strides,
-                      dtype, causal, softmax_scale, descale, stream);
+    return fa_fwd_ex(q, k, v, o, lse, B, H, H, S, S, D, q_strides, k_strides, v_strides, o_strides,
+                     dtype, causal, softmax_scale, descale, stream);
 }
 
-int fa_fwd_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
-               int B, int H, int H_kv, int S, int D,
-               const int64_t* q_strides, const int64_t* k_strides,
-               const int64_t* v_strides, const int64_t* o_strides,
-               int dtype, int causal, float softmax_scale,
-               const float* descale, void* stream)
+int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+              int B, int H, int H_kv, int S, int S_k, int D,
+              const int64_t* q_strides, const int64_t* k_strides,
+              const int64_t* v_strides, const int64_t* o_strides,
+              int dtype, int causal, float softmax_scale,
+              const float* descale, void* stream)
 {
     g_err[0] = 0;
     if (dtype == FA_DTYPE_FP8_E4M3)
@@ -200,19 +200,22 @@ int fa_fwd_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
     if (B == 0 || H == 0 || S == 0) return FA_OK;        // empty problem: nothing to do
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
+    if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
+    if (causal && S_k < S)
+        return fail(FA_ERR_BAD_SHAPE, "causal mask (bottom-right aligned) needs S_k >= S_q; got S_q=%d, S_k=%d", S, S_k);
     if (!q || !k || !v || !o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
 
     fa::FwdParams p;
     memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
-    p.B = B; p.H = H; p.S = S;
+    p.B = B; p.H = H; p.S = S; p.Sk = S_k;
     p.G = H / H_kv;
     p.dv = D;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.bh = B * H;
     if (!set_strides(q_strides, H, S, D, p.q_sb, p.q_sh, p.q_ss) ||
-        !set_strides(k_strides, H_kv, S, D, p.k_sb, p.k_sh, p.k_ss) ||
-        !set_strides(v_strides, H_kv, S, D, p.v_sb, p.v_sh, p.v_ss) ||
+        !set_strides(k_strides, H_kv, S_k, D, p.k_sb, p.k_sh, p.k_ss) ||
+        !set_strides(v_strides, H_kv, S_k, D, p.v_sb, p.v_sh, p.v_ss) ||
         !set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss))
         return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
     const long long esz = 2;
@@ -225,8 +228,8 @@ int fa_fwd_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
         if (reinterpret_cast<uintptr_t>(ptr) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "tensor base pointer not 16-byte aligned");
     // 32-bit buffer offsets inside one (batch, head) slice, with room for two prefetched tiles
     const long long max_ss = std::max(std::max(p.q_ss, p.k_ss), std::max(p.v_ss, p.o_ss));
-    if (((long long)S + 4 * fa::kBN) * max_ss * esz >= (1ll << 31))
-        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", S, max_ss);
+    if (((long long)std::max(S, S_k) + 4 * fa::kBN) * max_ss * esz >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", std::max(S, S_k), max_ss);
 
     const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
     // descale (used by fa_fwd_fp8 on its converted tensors): q and k scales fold into the softmax scale,
@@ -264,15 +267,15 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
                int causal, float softmax_scale, const float* descale,
                void* workspace, size_t workspace_bytes, void* stream)
 {
-    return fa_fwd_fp8_gqa(q, k, v, o, lse, B, H, H, S, D, q_strides, k_strides, v_strides, o_strides,
-                          causal, softmax_scale, descale, workspace, workspace_bytes, stream);
+    return fa_fwd_fp8_ex(q, k, v, o, lse, B, H, H, S, S, D, q_strides, k_strides, v_strides, o_strides,
+                         causal, softmax_scale, descale, workspace, workspace_bytes, stream);
 }
 
-int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
-                   int B, int H, int H_kv, int S, int D,
-                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
-                   int causal, float softmax_scale, const float* descale,
-                   void* workspace, size_t workspace_bytes, void* stream)
+int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int B, int H, int H_kv, int S, int S_k, int D,
+                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                  int causal, float softmax_scale, const float* descale,
+                  void* workspace, size_t workspace_bytes, void* stream)
 {
     g_err[0] = 0;
     if (!fa_supported(FA_DTYPE_FP8_E4M3, D))
@@ -281,6 +284,9 @@ int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* 
     if (B == 0 || H == 0 || S == 0) return FA_OK;
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
+    if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
+    if (causal && S_k < S)
+        return fail(FA_ERR_BAD_SHAPE, "causal mask (bottom-right aligned) needs S_k >= S_q; got S_q=%d, S_k=%d", S, S_k);
     if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
 #if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
     const bool native_qk = false;
@@ -290,7 +296,8 @@ int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* 
     const bool native_qk = D > 64;
 #endif
     const int heads[3] = {H, H_kv, H_kv};
-    const size_t one_q = (size_t)B * H * S * D * 2, one_kv = (size_t)B * H_kv * S * D * 2;   // bf16 copies
+    const int rows[3] = {S, S_k, S_k};
+    const size_t one_q = (size_t)B * H * S * D * 2, one_kv = (size_t)B * H_kv * S_k * D * 2;   // bf16 copies
     const size_t need = native_qk ? one_kv : one_q + 2 * one_kv;
     if (workspace_bytes < need)
         return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
@@ -300,7 +307,7 @@ int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     long long st[3][3];
     for (int t = 0; t < 3; ++t) {
-        if (!set_strides(strd[t], heads[t], S, D, st[t][0], st[t][1], st[t][2])) return fail(FA_ERR_BAD_STRIDE, "bad strides");
+        if (!set_strides(strd[t], heads[t], rows[t], D, st[t][0], st[t][1], st[t][2])) return fail(FA_ERR_BAD_STRIDE, "bad strides");
         if (st[t][0] % 16 || st[t][1] % 16 || st[t][2] % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
             return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
     }
@@ -309,36 +316,36 @@ int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* 
     char* wt[3] = {w, w + one_q, w + one_q + one_kv};   // the workspace holds the converted tensors back to back
     if (native_qk) wt[2] = w;
     for (int t = native_qk ? 2 : 0; t < 3; ++t) {
-        const int per_slice = S * (D / 16);
+        const int per_slice = rows[t] * (D / 16);
         const int bx = std::max(1, std::min((per_slice + 255) / 256, 64));
         hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(bx, B * heads[t]), dim3(256), 0, s,
                            reinterpret_cast<const unsigned char*>(src[t]),
                            reinterpret_cast<unsigned short*>(wt[t]),
-                           D, heads[t], S, st[t][0], st[t][1], st[t][2]);
+                           D, heads[t], rows[t], st[t][0], st[t][1], st[t][2]);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fp8 conversion launch failed: %s", hipGetErrorString(e));
     }
     if (!native_qk)
-        return fa_fwd_gqa(wt[0], wt[1], wt[2], o, lse, B, H, H_kv, S, D, nullptr, nullptr, nullptr, o_strides,
-                          FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
+        return fa_fwd_ex(wt[0], wt[1], wt[2], o, lse, B, H, H_kv, S, S_k, D, nullptr, nullptr, nullptr, o_strides,
+                         FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
 
     if (!o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
     fa::FwdParams p;
     memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = w; p.o = o; p.lse = lse;
-    p.B = B; p.H = H; p.S = S; p.dv = D;
+    p.B = B; p.H = H; p.S = S; p.Sk = S_k; p.dv = D;
     p.G = H / H_kv;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.bh = B * H;
     p.q_sb = st[0][0]; p.q_sh = st[0][1]; p.q_ss = st[0][2];
     p.k_sb = st[1][0]; p.k_sh = st[1][1]; p.k_ss = st[1][2];
-    p.v_ss = D; p.v_sh = (long long)S * D; p.v_sb = (long long)H_kv * S * D;
+    p.v_ss = D; p.v_sh = (long long)S_k * D; p.v_sb = (long long)H_kv * S_k * D;
     if (!set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss)) return fail(FA_ERR_BAD_STRIDE, "bad output strides");
     if ((p.o_sb * 2) % 16 || (p.o_sh * 2) % 16 || (p.o_ss * 2) % 16 || reinterpret_cast<uintptr_t>(o) % 16)
         return fail(FA_ERR_BAD_STRIDE, "output rows must be 16-byte aligned");
     const long long max_ss = std::max(std::max(p.q_ss, p.k_ss), std::max(2 * p.v_ss, 2 * p.o_ss));
-    if (((long long)S + 4 * fa::kBN) * max_ss >= (1ll << 31))
-        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d)", S);
+    if (((long long)std::max(S, S_k) + 4 * fa::kBN) * max_ss >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d)", std::max(S, S_k));
     const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
     const float dq = descale ? descale[0] : 1.f, dkk = descale ? descale[1] : 1.f, dvv = descale ? descale[2] : 1.f;
     p.scale = scale * dq * dkk;

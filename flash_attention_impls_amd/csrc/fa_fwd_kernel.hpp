@@ -45,7 +45,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct FwdParams {
     const void* q; const void* k; const void* v; void* o; float* lse;
-    int B, H, S;
+    int B, H, S;             // S: query rows
+    int Sk;                  // keys (= S for the reference's operator); causal mask bottom-right aligned: key <= query + Sk - S
     int G;                   // query heads per key/value head (1 = the reference's case): K, V have H / G heads
     int dv;                  // valid head_dim (a multiple of 16, <= the kernel's compiled D): columns dv .. D-1 of every
                              // Q / K / V row are read as zeros (buffer offsets pushed out of range) and not stored in O
@@ -267,6 +268,8 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;
+    const int Sk = p.Sk;
+    const int coff = CAUSAL ? Sk - S : 0;      // key <= query + coff
     const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
@@ -276,8 +279,8 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
     const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * 2);
-    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + p.dv) * 2);
-    const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + p.dv) * 2);
+    const unsigned k_bytes = (unsigned)(((long long)(Sk - 1) * p.k_ss + p.dv) * 2);
+    const unsigned v_bytes = (unsigned)(((long long)(Sk - 1) * p.v_ss + p.dv) * 2);
     __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem_t*>(qh), 0, q_bytes, 0x00020000);
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
@@ -304,9 +307,9 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     }
     const int q_first = q0[0], q_last = q0[QB - 1];
 
-    const int kv_end_wg = CAUSAL ? min(S, qb * kBM + kBM) : S;
+    const int kv_end_wg = CAUSAL ? min(Sk, qb * kBM + kBM + coff) : Sk;
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
-    const int kv_end_w = (q_first >= S) ? 0 : (CAUSAL ? min(S, q_last + 32) : S);
+    const int kv_end_w = (q_first >= S) ? 0 : (CAUSAL ? min(Sk, q_last + 32 + coff) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[row0 + r][16 ks + 8 hh + 0..7]
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const bool dead = (key >= S) || (CAUSAL && key > qrow);
+                const bool dead = (key >= Sk) || (CAUSAL && key > qrow + coff);
                 if (dead) st.sv[i] = -INFINITY;
             }
         }
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
 
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     // first block whose softmax needs the mask (causal diagonal of the wave's first row block, or ragged end)
-    const int mb = min(CAUSAL ? (q_first >> 5) : 0x7fffffff, S >> 5);
+    const int mb = min(CAUSAL ? ((q_first + coff) >> 5) : 0x7fffffff, Sk >> 5);
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
     int j = 0;
     if (NT > 0) {
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                            if ((key >= S) || (CAUSAL && key > qrow)) sx[i] = -INFINITY;
+                            if ((key >= Sk) || (CAUSAL && key > qrow + coff)) sx[i] = -INFINITY;
                         }
                         float mx = fmaxf(sx[0], sx[1]);
 #pragma unroll

@@ -81,7 +81,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     if (head >= p.bh) return;
     const int b = head / p.H;
     const int h = head - b * p.H;
-    const int S = p.S;
+    const int S = p.S;                         // query rows
+    const int Sk = p.Sk;                       // keys
+    const int coff = CAUSAL ? Sk - S : 0;      // bottom-right aligned causal mask: key <= query + coff (>= 0, host-checked)
     const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
 
     const unsigned q_bytes = (unsigned)(((long long)(S - 1) * p.q_ss + p.dv) * QKB);
-    const unsigned k_bytes = (unsigned)(((long long)(S - 1) * p.k_ss + p.dv) * QKB);
-    const unsigned v_bytes = (unsigned)(((long long)(S - 1) * p.v_ss + p.dv) * 2);
+    const unsigned k_bytes = (unsigned)(((long long)(Sk - 1) * p.k_ss + p.dv) * QKB);
+    const unsigned v_bytes = (unsigned)(((long long)(Sk - 1) * p.v_ss + p.dv) * 2);
     __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qh), 0, q_bytes, 0x00020000);
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
@@ -113,9 +115,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int rowblk_of_wave = CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave;
     const int q0w = qb * kBM + rowblk_of_wave * 32;
 
-    const int kv_end_wg = CAUSAL ? min(S, qb * kBM + kBM) : S;
+    const int kv_end_wg = CAUSAL ? min(Sk, qb * kBM + kBM + coff) : Sk;
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
-    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? min(S, q0w + 32) : S);
+    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? min(Sk, q0w + 32 + coff) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
     auto load_q = [&](int qblk) {
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = key0 + 16 * kt + 4 * lg + e;
-                if ((key >= S) || (CAUSAL && key > qrow)) sv[e] = -INFINITY;
+                if ((key >= Sk) || (CAUSAL && key > qrow + coff)) sv[e] = -INFINITY;
             }
         }
         const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[0], c, -m_c[qt]));
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
                     float v = s_acc[par][kt][qt][e];
                     if constexpr (MASK) {
                         const int key = key0 + 16 * kt + 4 * lg + e;
-                        if ((key >= S) || (CAUSAL && key > qrow)) v = -INFINITY;
+                        if ((key >= Sk) || (CAUSAL && key > qrow + coff)) v = -INFINITY;
                     }
                     mx = fmaxf(mx, v);
                 }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
     const int NT = my_nt;                          // 64-key tiles this wave computes on
-    const int mb = min(CAUSAL ? (q0w >> 5) : 0x7fffffff, S >> 5);   // first block whose softmax needs the mask
+    const int mb = min(CAUSAL ? ((q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block whose softmax needs the mask
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
     int j = 0;
     if (NT > 0) {
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int key = key0 + 16 * kt + 4 * lg + e;
-                                if ((key >= S) || (CAUSAL && key > qrow)) sx[kt][qt][e] = -INFINITY;
+                                if ((key >= Sk) || (CAUSAL && key > qrow + coff)) sx[kt][qt][e] = -INFINITY;
                                 mx = fmaxf(mx, sx[kt][qt][e]);
                             }
                         mx = fmaxf(mx, __shfl_xor(mx, 16));

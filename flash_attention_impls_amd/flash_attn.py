@@ -96,13 +96,13 @@ def _declare(lib):
     lib.fa_bwd.restype = c.c_int
     lib.fa_bwd.argtypes = [c.c_void_p] * 9 + [c.c_int] * 4 + [c.POINTER(c.c_int64)] * 8 + \
         [c.c_int, c.c_int, c.c_float, c.c_void_p, c.c_size_t, c.c_void_p]
-    # grouped-query variants: the same signatures with H_kv after H
-    lib.fa_fwd_gqa.restype = c.c_int
-    lib.fa_fwd_gqa.argtypes = lib.fa_fwd.argtypes[:7] + [c.c_int] + lib.fa_fwd.argtypes[7:]
-    lib.fa_fwd_fp8_gqa.restype = c.c_int
-    lib.fa_fwd_fp8_gqa.argtypes = lib.fa_fwd_fp8.argtypes[:7] + [c.c_int] + lib.fa_fwd_fp8.argtypes[7:]
-    lib.fa_bwd_gqa.restype = c.c_int
-    lib.fa_bwd_gqa.argtypes = lib.fa_bwd.argtypes[:11] + [c.c_int] + lib.fa_bwd.argtypes[11:]
+    # extended variants: (B, H, H_kv, S_q, S_k, D) instead of (B, H, S, D)
+    lib.fa_fwd_ex.restype = c.c_int
+    lib.fa_fwd_ex.argtypes = lib.fa_fwd.argtypes[:5] + [c.c_int] * 6 + lib.fa_fwd.argtypes[9:]
+    lib.fa_fwd_fp8_ex.restype = c.c_int
+    lib.fa_fwd_fp8_ex.argtypes = lib.fa_fwd_fp8.argtypes[:5] + [c.c_int] * 6 + lib.fa_fwd_fp8.argtypes[9:]
+    lib.fa_bwd_ex.restype = c.c_int
+    lib.fa_bwd_ex.argtypes = lib.fa_bwd.argtypes[:9] + [c.c_int] * 6 + lib.fa_bwd.argtypes[13:]
     lib.fa_fwd_dispatch.restype = c.c_int
     lib.fa_fwd_dispatch.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                     c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p]
@@ -176,12 +176,14 @@ def check_args(q, k, v) -> None:
             raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
     if q.dim() != 4:
         raise FlashAttnArgumentError(f"q must be (B, H, N, D); got shape {tuple(q.shape)}")
-    # the reference takes (B, H, N, D) from q for all three tensors (FA2-triton.py:176); grouped-query attention (k, v
-    # with H_kv heads, H % H_kv == 0: query head h uses key/value head h // (H // H_kv)) is this build's extension
-    if k.dim() != 4 or v.shape != k.shape or k.shape[0] != q.shape[0] or k.shape[2:] != q.shape[2:] \
-            or k.shape[1] == 0 or q.shape[1] % k.shape[1] != 0:
+    # the reference takes (B, H, N, D) from q for all three tensors (FA2-triton.py:176).  This build's extensions:
+    # grouped-query attention (k, v with H_kv heads, H % H_kv == 0: query head h uses key/value head h // (H // H_kv))
+    # and a key/value length of its own (k, v with N_k >= 1 rows; the causal mask is then bottom-right aligned)
+    if k.dim() != 4 or v.shape != k.shape or k.shape[0] != q.shape[0] or k.shape[3] != q.shape[3] \
+            or (q.shape[1] != 0 if k.shape[1] == 0 else q.shape[1] % k.shape[1] != 0) \
+            or (k.shape[2] == 0 and q.shape[2] != 0):
         raise FlashAttnArgumentError(
-            "q, k, v must have identical shapes (or k, v the same shape with a head count that divides q's); "
+            "q, k, v must have identical shapes (or k, v one shape (B, H_kv, N_k, D) with H_kv dividing q's head count); "
             f"got {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
     if k.dtype != q.dtype or v.dtype != q.dtype:
         raise FlashAttnArgumentError(f"q, k, v must share a dtype; got {q.dtype}, {k.dtype}, {v.dtype}")
@@ -200,7 +202,7 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     """Launch the forward on kernel-ready tensors (head_dim 64 or 128).  Returns (o, lse or None)."""
     code = _dtype_code(q.dtype)
     B, H, N, D = q.shape
-    Hkv = k.shape[1]
+    Hkv, Nk = k.shape[1], k.shape[2]
     out_dtype = torch.bfloat16 if code == FA_DTYPE_FP8_E4M3 else q.dtype
     o = torch.empty((B, H, N, D), dtype=out_dtype, device=q.device)        # FA2-triton.py:179
     lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if want_lse else None
@@ -211,15 +213,15 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
         stream = torch.cuda.current_stream().cuda_stream
         lse_ptr = lse.data_ptr() if lse is not None else None
         if code == FA_DTYPE_FP8_E4M3:
-            nbytes = lib.fa_fp8_workspace_bytes(B, H, N, D)
+            nbytes = lib.fa_fp8_workspace_bytes(B, H, max(N, Nk), D)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-            rc = lib.fa_fwd_fp8_gqa(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
-                                    B, H, Hkv, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
-                                    1 if causal else 0, scale, dsc, ws.data_ptr(), nbytes, stream)
+            rc = lib.fa_fwd_fp8_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
+                                   B, H, Hkv, N, Nk, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                                   1 if causal else 0, scale, dsc, ws.data_ptr(), nbytes, stream)
         else:
-            rc = lib.fa_fwd_gqa(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
-                                B, H, Hkv, N, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
-                                code, 1 if causal else 0, scale, dsc, stream)
+            rc = lib.fa_fwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse_ptr,
+                               B, H, Hkv, N, Nk, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o),
+                               code, 1 if causal else 0, scale, dsc, stream)
     if rc != 0:
         raise RuntimeError(f"fa_fwd failed ({rc}): {lib.fa_last_error().decode()}")
     return o, lse
@@ -229,9 +231,9 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     """Launch the backward (pre-pass + dQ kernel + dK/dV kernel).  Returns (dq, dk, dv), each written once."""
     code = _dtype_code(q.dtype)
     B, H, N, D = q.shape
-    Hkv = k.shape[1]
+    Hkv, Nk = k.shape[1], k.shape[2]
     dq = torch.empty_like(o)                                                        # contiguous, like o
-    dk = torch.empty((B, Hkv, N, D), dtype=o.dtype, device=o.device)
+    dk = torch.empty((B, Hkv, Nk, D), dtype=o.dtype, device=o.device)
     dv = torch.empty_like(dk)
     if B * H * N == 0:
         return dq, dk, dv
@@ -240,11 +242,11 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
         stream = torch.cuda.current_stream().cuda_stream
         nbytes = lib.fa_bwd_workspace_bytes(B, H, N)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-        rc = lib.fa_bwd_gqa(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-                            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Hkv, N, D,
-                            _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(do),
-                            _strides3(dq), _strides3(dk), _strides3(dv),
-                            code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
+        rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Hkv, N, Nk, D,
+                           _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(do),
+                           _strides3(dq), _strides3(dk), _strides3(dv),
+                           code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
     if rc != 0:
         raise RuntimeError(f"fa_bwd failed ({rc}): {lib.fa_last_error().decode()}")
     return dq, dk, dv
@@ -274,7 +276,9 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
                softmax_scale: float | None = None, return_lse: bool = False,
                descale: tuple[float, float, float] | None = None):
     """Fused attention forward on MI355X.  ``q, k, v``: (B, H, N, D) GPU tensors; ``k, v`` may have fewer heads
-    (B, H_kv, N, D) with H % H_kv == 0 (grouped-query / multi-query attention; dk, dv then have H_kv heads too).
+    (B, H_kv, N_k, D) with H % H_kv == 0 (grouped-query / multi-query attention; dk, dv then have H_kv heads too) and a
+    length N_k of their own; with ``causal`` the mask is then bottom-right aligned (key j visible to query i iff
+    j <= i + N_k - N) and needs N_k >= N.
 
     Returns O with q's dtype (fp32 inputs are computed in fp16 and cast back, like the
     reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural

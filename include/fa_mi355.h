@@ -18,10 +18,10 @@
  *   fa_bwd                 <- _FlashAttnFn.backward + _bwd_kernel launch
  *                             code/triton_fa2/FA2-triton.py:207-237 (q,k,v, the forward's statistics and dO in;
  *                             dQ,dK,dV out -- written once each, no zero-fill and no atomics needed)
- *   fa_fwd_gqa, fa_fwd_fp8_gqa, fa_bwd_gqa
- *                          <- no reference counterpart (its operator takes B, H, N, D from q for all three tensors, FA2-triton.py:176,185-194):
- *                             the same three entry points for K / V with fewer heads than Q (grouped-query and
- *                             multi-query attention); H_kv == H is exactly fa_fwd / fa_fwd_fp8 / fa_bwd
+ *   fa_fwd_ex, fa_fwd_fp8_ex, fa_bwd_ex
+ *                          <- no reference counterpart (its operator takes B, H, N, D from q for all three tensors,
+ *                             FA2-triton.py:176,185-194): the same three entry points for K / V with fewer heads than Q
+ *                             (grouped-query / multi-query attention) and / or another length
  *
  * Conventions
  *   - all tensor pointers are DEVICE pointers owned by the caller; the library never
@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 120          /* 0.1.2: + grouped-query entry points (0.1.1: + backward) */
+#define FA_VERSION 120          /* 0.1.2: + extended entry points (H_kv, S_k) (0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -138,33 +138,38 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
            void* workspace, size_t workspace_bytes, void* stream);
 
 /*
- * Grouped-query / multi-query variants: Q, O, dO, dQ and LSE have H heads, K, V, dK, dV have H_kv heads, H % H_kv == 0;
- * query head h attends to key/value head h / (H / H_kv) (consecutive query heads share one).  Everything else is as in
- * the entry point of the same name; the strides of K, V, dK, dV address [B, H_kv, S, D] tensors (NULL = contiguous
- * with H_kv heads).  dK and dV are the sums over the query heads of the group, accumulated in registers by one
- * workgroup per (key block, key/value head): still no atomics, no zero-fill, bitwise deterministic.
- * Workspaces: fa_fp8_workspace_bytes(B, H, S, D) and fa_bwd_workspace_bytes(B, H, S) with the QUERY head count are sufficient.
+ * Extended entry points: key/value head count and key count of their own.
+ *   H_kv : Q, O, dO, dQ and LSE have H heads, K, V, dK, dV have H_kv heads, H % H_kv == 0; query head h attends to
+ *          key/value head h / (H / H_kv) (grouped-query / multi-query attention: consecutive query heads share one).
+ *   S_k  : Q, O, dO, dQ, LSE have S_q rows, K, V, dK, dV have S_k rows (S_k >= 1).  The causal mask is then
+ *          bottom-right aligned -- key j is visible to query i iff j <= i + S_k - S_q (the last query sees every key:
+ *          chunked prefill / decoding against a longer key/value history) -- and needs S_k >= S_q.
+ * Everything else is as in the entry point of the same name; the strides of K, V, dK, dV address [B, H_kv, S_k, D]
+ * tensors (NULL = contiguous).  dK and dV are the sums over the query heads of the group, accumulated in registers by
+ * one workgroup per (key block, key/value head): still no atomics, no zero-fill, bitwise deterministic.
+ * H_kv == H and S_k == S_q is exactly fa_fwd / fa_fwd_fp8 / fa_bwd.
+ * Workspaces: fa_fp8_workspace_bytes(B, H, max(S_q, S_k), D) and fa_bwd_workspace_bytes(B, H, S_q) are sufficient.
  */
-int fa_fwd_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
-               int B, int H, int H_kv, int S, int D,
-               const int64_t* q_strides, const int64_t* k_strides,
-               const int64_t* v_strides, const int64_t* o_strides,
-               int dtype, int causal, float softmax_scale,
-               const float* descale, void* stream);
-int fa_fwd_fp8_gqa(const void* q, const void* k, const void* v, void* o, float* lse,
-                   int B, int H, int H_kv, int S, int D,
-                   const int64_t* q_strides, const int64_t* k_strides,
-                   const int64_t* v_strides, const int64_t* o_strides,
-                   int causal, float softmax_scale, const float* descale,
-                   void* workspace, size_t workspace_bytes, void* stream);
-int fa_bwd_gqa(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-               void* dq, void* dk, void* dv,
-               int B, int H, int H_kv, int S, int D,
-               const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
-               const int64_t* o_strides, const int64_t* do_strides,
-               const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
-               int dtype, int causal, float softmax_scale,
-               void* workspace, size_t workspace_bytes, void* stream);
+int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+              int B, int H, int H_kv, int S_q, int S_k, int D,
+              const int64_t* q_strides, const int64_t* k_strides,
+              const int64_t* v_strides, const int64_t* o_strides,
+              int dtype, int causal, float softmax_scale,
+              const float* descale, void* stream);
+int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int B, int H, int H_kv, int S_q, int S_k, int D,
+                  const int64_t* q_strides, const int64_t* k_strides,
+                  const int64_t* v_strides, const int64_t* o_strides,
+                  int causal, float softmax_scale, const float* descale,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+              void* dq, void* dk, void* dv,
+              int B, int H, int H_kv, int S_q, int S_k, int D,
+              const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+              const int64_t* o_strides, const int64_t* do_strides,
+              const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
+              int dtype, int causal, float softmax_scale,
+              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Launch geometry that fa_fwd would use (for benches / profilers): writes grid size,

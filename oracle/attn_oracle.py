@@ -90,18 +90,21 @@ def sdpa_oracle(q, k, v, causal: bool = False, scale: float | None = None):
 # attention_baseline_kernel restatement in float64 (test_flash_attn.cu:548-615)
 # --------------------------------------------------------------------------
 def naive_attention_f64(q, k, v, causal: bool = False, scale: float | None = None):
-    """q,k,v: numpy (B,H,N,D) any float dtype. Returns (o f64, lse f64)."""
+    """q,k,v: numpy (B,H,N,D) any float dtype. Returns (o f64, lse f64).
+    k, v may have another length N_k (not a reference case: its q, k, v share one N); the causal mask is then
+    bottom-right aligned, key j visible to query i iff j <= i + N_k - N (for N_k == N the reference's rule)."""
     q = np.asarray(q, dtype=np.float64)
     k = np.asarray(k, dtype=np.float64)
     v = np.asarray(v, dtype=np.float64)
     B, H, N, D = q.shape
+    Nk = k.shape[2]
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     s = np.einsum("bhid,bhjd->bhij", q, k) * scale       # pass 1 :575-586
     if causal:
         i = np.arange(N)[:, None]
-        j = np.arange(N)[None, :]
-        s = np.where(j > i, -np.inf, s)                  # FA2-triton.py:70-73
+        j = np.arange(Nk)[None, :]
+        s = np.where(j > i + (Nk - N), -np.inf, s)       # FA2-triton.py:70-73
     m = s.max(axis=-1, keepdims=True)                    # :588-592
     p = np.exp(s - m)                                    # pass 2 :594-600
     l = p.sum(axis=-1, keepdims=True)
@@ -184,19 +187,21 @@ def tiled_online_softmax(q, k, v, causal: bool = False, scale: float | None = No
 # --------------------------------------------------------------------------
 def naive_attention_bwd_f64(q, k, v, do, causal: bool = False, scale: float | None = None):
     """Closed-form float64 gradients of o = softmax(scale q k^T [+mask]) v.
-    q,k,v,do: numpy (B,H,N,D).  Returns (dq, dk, dv, delta) in float64, delta = rowsum(do*o)."""
+    q,k,v,do: numpy (B,H,N,D).  Returns (dq, dk, dv, delta) in float64, delta = rowsum(do*o).
+    k, v may have another length N_k (bottom-right aligned causal mask, as in naive_attention_f64)."""
     q = np.asarray(q, dtype=np.float64)
     k = np.asarray(k, dtype=np.float64)
     v = np.asarray(v, dtype=np.float64)
     do = np.asarray(do, dtype=np.float64)
     B, H, N, D = q.shape
+    Nk = k.shape[2]
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     s = np.einsum("bhid,bhjd->bhij", q, k) * scale                   # :147
     if causal:
         i = np.arange(N)[:, None]
-        j = np.arange(N)[None, :]
-        s = np.where(j > i, -np.inf, s)                              # :148-151
+        j = np.arange(Nk)[None, :]
+        s = np.where(j > i + (Nk - N), -np.inf, s)                   # :148-151
     m = s.max(axis=-1, keepdims=True)
     p = np.exp(s - m)
     p /= p.sum(axis=-1, keepdims=True)                               # :156 (exp(qk-m)/l)

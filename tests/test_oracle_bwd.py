@@ -87,3 +87,27 @@ def test_mfma_rounding_model_within_tolerance():
         ref = d[key]
         rel = np.linalg.norm(g - ref) / np.linalg.norm(ref)
         assert rel < 6e-3, (key, rel)
+
+
+def test_oracle_other_key_length_is_the_tail_of_the_square_problem():
+    """N_k != N (not a reference case): with the bottom-right aligned causal mask, the N queries against N_k keys are
+    exactly the last N queries of the square N_k problem -- which ties this extension of the oracle to the part the
+    reference's fixtures pin.  Gradients: dq of those rows; dk, dv when only those rows carry an upstream gradient."""
+    rng = np.random.default_rng(7)
+    B, H, N, Nk, D = 1, 2, 37, 90, 32
+    qf, k, v, dof = [rng.standard_normal((B, H, Nk, D)) for _ in range(4)]
+    q, do = qf[:, :, Nk - N:], dof[:, :, Nk - N:]
+    o, lse = orc.naive_attention_f64(q, k, v, causal=True)
+    o_sq, lse_sq = orc.naive_attention_f64(qf, k, v, causal=True)
+    assert np.array_equal(o, o_sq[:, :, Nk - N:]) and np.array_equal(lse, lse_sq[:, :, Nk - N:])
+    do_masked = dof.copy()
+    do_masked[:, :, :Nk - N] = 0.0
+    dq, dk, dv, _ = orc.naive_attention_bwd_f64(q, k, v, do, causal=True)
+    dq_sq, dk_sq, dv_sq, _ = orc.naive_attention_bwd_f64(qf, k, v, do_masked, causal=True)
+    assert np.allclose(dq, dq_sq[:, :, Nk - N:], rtol=0, atol=1e-13)
+    assert np.allclose(dk, dk_sq, rtol=0, atol=1e-13) and np.allclose(dv, dv_sq, rtol=0, atol=1e-13)
+    # non-causal: plain cross attention, every key visible
+    o_nc, _ = orc.naive_attention_f64(q, k, v, causal=False)
+    s = np.einsum("bhid,bhjd->bhij", q, k) / np.sqrt(D)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    assert np.allclose(o_nc, np.einsum("bhij,bhjd->bhid", p / p.sum(-1, keepdims=True), v), atol=1e-14)
