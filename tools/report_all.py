@@ -1,6 +1,8 @@
 """All BASELINE.json single-GPU configurations with the reference harness' semantics
 (measure_latency: 10 warm-ups, 100 per-iteration event timings, mean/std/min; code/triton_fa2/FA2-triton.py:249-268,
-340-354): ms, TFLOP/s, % of the dense bf16 MFMA peak, algorithmic GB/s, tokens/s, peak memory, max|o - SDPA|."""
+340-354): ms, TFLOP/s, % of the dense bf16 MFMA peak, algorithmic GB/s, tokens/s, peak memory, max|o - SDPA|.
+Last column: the same launch replayed from a captured HIP graph (100 launches per replay, per-launch ms) -- what the
+kernel costs once the Python / ctypes call is out of the way; it matters for the small, launch-bound shapes."""
 import math
 import os
 import sys
@@ -24,10 +26,34 @@ CONFIGS = [
 ]
 
 
+def graph_latency(fn, launches=100, replays=5):
+    """Per-launch ms of fn replayed from a HIP graph holding `launches` back-to-back launches (min over replays)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(launches):
+            fn()
+    graph.replay()
+    torch.cuda.synchronize()
+    best = float("inf")
+    for _ in range(replays):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        b.synchronize()
+        best = min(best, a.elapsed_time(b) / launches)
+    return best
+
+
 def main():
     print(torch.cuda.get_device_name(0))
     print(f"{'config':26s} {'shape':22s} {'dtype':13s} {'causal':6s} {'mean ms':>9s} {'std':>7s} {'min ms':>8s} "
-          f"{'TFLOP/s':>8s} {'%peak':>6s} {'GB/s':>7s} {'Mtok/s':>8s} {'peakMB':>8s} {'max|o-sdpa|':>11s}", flush=True)
+          f"{'TFLOP/s':>8s} {'%peak':>6s} {'GB/s':>7s} {'Mtok/s':>8s} {'peakMB':>8s} {'max|o-sdpa|':>11s} {'graph ms':>9s}", flush=True)
     for name, B, H, S, D, dt, causal in CONFIGS:
         torch.manual_seed(0)
         f32 = [torch.randn(B, H, S, D, device="cuda") for _ in range(3)]
@@ -48,13 +74,14 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         m = measure_latency(lambda: flash_attn(q, k, v, causal, descale=descale), warmup=10, iters=100)
         peak_mb = torch.cuda.max_memory_allocated() / 1e6
+        graph_ms = graph_latency(lambda: flash_attn(q, k, v, causal, descale=descale))
         fl = attn_flops(B, H, S, D, causal)
         by = attn_bytes(B, H, S, D, in_bytes=q.element_size())
         sec = m["mean_ms"] * 1e-3
         tf = fl / sec / 1e12
         print(f"{name:26s} {str((B, H, S, D)):22s} {str(dt)[6:]:13s} {str(causal):6s} {m['mean_ms']:9.4f} "
               f"{m['std_ms']:7.4f} {m['min_ms']:8.4f} {tf:8.1f} {100 * tf / 2516.6:6.1f} {by / sec / 1e9:7.0f} "
-              f"{B * H * S / sec / 1e6:8.1f} {peak_mb:8.0f} {err:11.3e}", flush=True)
+              f"{B * H * S / sec / 1e6:8.1f} {peak_mb:8.0f} {err:11.3e} {graph_ms:9.4f}", flush=True)
 
 
 if __name__ == "__main__":
