@@ -7,7 +7,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <mutex>
 
 #include "../../include/fa_mi355.h"
 #include "fa_capi_common.hpp"
@@ -24,12 +23,9 @@ template <class T, int D, int MODE, bool CAUSAL>
 int launch_bwd(const fa::BwdParams& p, int grid, hipStream_t stream)
 {
     constexpr int lds = fa::bwd_lds_bytes<D, MODE>();
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_bwd_kernel<T, D, MODE, CAUSAL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    auto* kernel = &fa::fa_bwd_kernel<T, D, MODE, CAUSAL>;
+    struct Tag {};                                    // (local to this instantiation of the launcher)
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((fa::fa_bwd_kernel<T, D, MODE, CAUSAL>), dim3(grid), dim3(64 * fa::bwd_waves<MODE>()), lds, stream, p);
@@ -48,12 +44,9 @@ int launch_dkdv(const fa::BwdParams& p, int grid, hipStream_t stream)
     return launch_bwd<T, D, 1, CAUSAL>(p, grid, stream);
 #else
     constexpr int lds = fa::dkdv_lds_bytes<D>();
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    auto* kernel = &fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>;
+    struct Tag {};                                    // (local to this instantiation of the launcher)
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>), dim3(grid), dim3(512), lds, stream, p);

@@ -12,7 +12,6 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
-#include <mutex>
 
 #include "../../include/fa_mi355.h"
 #include "fa_capi_common.hpp"
@@ -37,12 +36,9 @@ template <class T, int D, bool CAUSAL>
 int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
 {
     constexpr int lds = fa::lds_bytes<D>();
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel<T, D, CAUSAL, kQB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    auto* kernel = &fa::fa_fwd_kernel<T, D, CAUSAL, kQB>;
+    struct Tag {};                                    // (local to this instantiation of the launcher)
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((fa::fa_fwd_kernel<T, D, CAUSAL, kQB>), dim3(grid), dim3(kThreads), lds, stream, p);
@@ -56,12 +52,9 @@ template <class T, bool CAUSAL, int D>
 int launch16(const fa::FwdParams& p, int grid, hipStream_t stream)
 {
     constexpr int lds = fa::lds_bytes<D>();
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel16<T, CAUSAL, false, D>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    auto* kernel = &fa::fa_fwd_kernel16<T, CAUSAL, false, D>;
+    struct Tag {};                                    // (local to this instantiation of the launcher)
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((fa::fa_fwd_kernel16<T, CAUSAL, false, D>), dim3(grid), dim3(512), lds, stream, p);
@@ -75,12 +68,9 @@ template <bool CAUSAL>
 int launch16_qk8(const fa::FwdParams& p, int grid, hipStream_t stream)
 {
     constexpr int lds = fa::lds_bytes<128>();
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&fa::fa_fwd_kernel16<fa::TypeBF16, CAUSAL, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
+    auto* kernel = &fa::fa_fwd_kernel16<fa::TypeBF16, CAUSAL, true>;
+    struct Tag {};                                    // (local to this instantiation of the launcher)
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((fa::fa_fwd_kernel16<fa::TypeBF16, CAUSAL, true>), dim3(grid), dim3(512), lds, stream, p);

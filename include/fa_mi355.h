@@ -29,7 +29,8 @@
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return value 0 = success, negative = error (see FA_ERR_*); a human-readable message
  *     for the calling thread is available from fa_last_error();
- *   - re-entrant: no mutable global state besides one-time kernel attribute setup.
+ *   - re-entrant: no mutable global state besides the one-time, per-device kernel attribute setup (a process may drive
+ *     several GPUs: the current device at the time of the call is the one used).
  */
 #ifndef FA_MI355_H
 #define FA_MI355_H
