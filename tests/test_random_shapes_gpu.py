@@ -48,3 +48,42 @@ def test_backward_random_shapes(case):
         got = leaf.grad.float().cpu().numpy()
         assert np.isfinite(got).all(), (case, key)
         assert np.abs(got - r).max() <= TOL[dt] * max(1.0, np.abs(r).max()), (case, key)
+
+
+# grouped key/value heads and a key/value length of its own (the extended entry points): G query heads per key/value
+# head, S_k = S + extra keys (extra >= 0 keeps the bottom-right aligned causal mask defined; non-causal cases may also
+# have fewer keys than queries)
+ext_shape = st.tuples(st.integers(1, 2), st.integers(1, 3), st.integers(1, 4), st.integers(1, 300), st.integers(-150, 260),
+                      st.sampled_from(list(range(16, 129, 16))), st.sampled_from(["bf16", "fp16"]), st.booleans(),
+                      st.integers(0, 2 ** 16))
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(ext_shape)
+def test_forward_backward_random_extended_shapes(case):
+    B, Hkv, G, S, extra, D, dt, causal, seed = case
+    Sk = max(1, S + (abs(extra) if causal else extra))
+    H = Hkv * G
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, H, S, D, generator=g).to(DT[dt]).cuda()
+    k = torch.randn(B, Hkv, Sk, D, generator=g).to(DT[dt]).cuda()
+    v = torch.randn(B, Hkv, Sk, D, generator=g).to(DT[dt]).cuda()
+    do = torch.randn(B, H, S, D, generator=g).to(DT[dt]).cuda()
+    leaves = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o, lse = fa.flash_attn(*leaves, causal, return_lse=True)
+    o.backward(do)
+    torch.cuda.synchronize()
+    ke, ve = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
+    qn, kn, vn, don = [t.float().cpu().numpy() for t in (q, ke, ve, do)]
+    ref, lse_ref = orc.naive_attention_f64(qn, kn, vn, causal=causal)
+    got = o.detach().float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= TOL[dt] * max(1.0, np.abs(ref).max()), case
+    assert np.abs(lse.detach().cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max()), case
+    dq_ref, dk_ref, dv_ref, _ = orc.naive_attention_bwd_f64(qn, kn, vn, don, causal=causal)
+    dk_ref = dk_ref.reshape(B, Hkv, G, Sk, D).sum(axis=2)
+    dv_ref = dv_ref.reshape(B, Hkv, G, Sk, D).sum(axis=2)
+    for leaf, r, key in zip(leaves, (dq_ref, dk_ref, dv_ref), ("dq", "dk", "dv")):
+        gotg = leaf.grad.float().cpu().numpy()
+        assert gotg.shape == r.shape and np.isfinite(gotg).all(), (case, key)
+        assert np.abs(gotg - r).max() <= TOL[dt] * max(1.0, np.abs(r).max()), (case, key)
