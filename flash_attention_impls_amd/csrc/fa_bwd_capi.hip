@@ -134,8 +134,6 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
     if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
-    if (causal && S_k < S)
-        return fail(FA_ERR_BAD_SHAPE, "causal mask (bottom-right aligned) needs S_k >= S_q; got S_q=%d, S_k=%d", S, S_k);
 #if defined(FA_BWD_DKDV_SINGLE)
     if (H_kv != H || S_k != S) return fail(FA_ERR_BAD_SHAPE, "this build's dK/dV kernel serves equal head counts and lengths only");
 #endif

@@ -44,7 +44,7 @@ struct BwdParams {
     const float* stats;                 // [2][B*H][Spad]: LSE*log2(e) (+inf past S), then -delta (0 past S)
     int B, H, S;                        // H, S: heads and rows of the stationary operands (= of the grid)
     int Sy;                             // rows of the streamed operands (MODE 0: keys, dK/dV kernel: queries)
-    int coff;                           // keys - queries: the causal mask is bottom-right aligned, key <= query + coff (>= 0)
+    int coff;                           // keys - queries: the causal mask is bottom-right aligned, key <= query + coff
     int G;                              // grouped-query attention, query heads per key/value head (1 = equal head counts).
                                         // MODE 0: H query heads, the streamed K / V have H / G heads (head h reads h / G);
                                         // dK/dV kernel: H key/value heads, G query heads (h G .. h G + G-1) are streamed
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     int blk_mask_lo = 0x7fffffff, blk_mask_hi = -1;      // blocks in [lo, hi] need the causal mask
     if constexpr (CAUSAL) {
         if constexpr (MODE == 0) {                        // queries stationary, keys streamed: keys <= query
-            j_end = min(nty, (min(Sy, min(S, x0 + XB) + coff) + kBN - 1) / kBN);
-            blk_end_w = (x0w >= S) ? 0 : (min(Sy, min(S, x0w + 32) + coff) + 31) / 32;
-            blk_mask_lo = (x0w + coff) >> 5;              // first block containing a key > the wave's first query (+ coff)
+            j_end = min(nty, (max(0, min(Sy, min(S, x0 + XB) + coff)) + kBN - 1) / kBN);
+            blk_end_w = (x0w >= S) ? 0 : (max(0, min(Sy, min(S, x0w + 32) + coff)) + 31) / 32;
+            blk_mask_lo = max(0, x0w + coff) >> 5;        // first block containing a key > the wave's first query (+ coff)
             blk_mask_hi = 0x7fffffff;
         } else {                                          // keys stationary, queries streamed: queries >= key
             j_begin = min(nty, x0 / kBN);

@@ -191,8 +191,6 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
     if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
-    if (causal && S_k < S)
-        return fail(FA_ERR_BAD_SHAPE, "causal mask (bottom-right aligned) needs S_k >= S_q; got S_q=%d, S_k=%d", S, S_k);
     if (!q || !k || !v || !o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
 
     fa::FwdParams p;
@@ -275,8 +273,6 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
     if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
-    if (causal && S_k < S)
-        return fail(FA_ERR_BAD_SHAPE, "causal mask (bottom-right aligned) needs S_k >= S_q; got S_q=%d, S_k=%d", S, S_k);
     if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
 #if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
     const bool native_qk = false;

@@ -307,9 +307,9 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     }
     const int q_first = q0[0], q_last = q0[QB - 1];
 
-    const int kv_end_wg = CAUSAL ? min(Sk, qb * kBM + kBM + coff) : Sk;
+    const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * kBM + kBM + coff)) : Sk;   // (coff < 0: the first -coff queries see no key)
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
-    const int kv_end_w = (q_first >= S) ? 0 : (CAUSAL ? min(Sk, q_last + 32 + coff) : Sk);
+    const int kv_end_w = (q_first >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q_last + 32 + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (r,hh) holds Q[row0 + r][16 ks + 8 hh + 0..7]
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
 
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     // first block whose softmax needs the mask (causal diagonal of the wave's first row block, or ragged end)
-    const int mb = min(CAUSAL ? ((q_first + coff) >> 5) : 0x7fffffff, Sk >> 5);
+    const int mb = min(CAUSAL ? (max(0, q_first + coff) >> 5) : 0x7fffffff, Sk >> 5);
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
     int j = 0;
     if (NT > 0) {

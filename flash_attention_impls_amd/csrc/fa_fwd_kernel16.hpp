@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int h = head - b * p.H;
     const int S = p.S;                         // query rows
     const int Sk = p.Sk;                       // keys
-    const int coff = CAUSAL ? Sk - S : 0;      // bottom-right aligned causal mask: key <= query + coff (>= 0, host-checked)
+    const int coff = CAUSAL ? Sk - S : 0;      // bottom-right aligned causal mask: key <= query + coff (coff < 0: queries without keys give O = 0, LSE = -inf)
     const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int rowblk_of_wave = CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave;
     const int q0w = qb * kBM + rowblk_of_wave * 32;
 
-    const int kv_end_wg = CAUSAL ? min(Sk, qb * kBM + kBM + coff) : Sk;
+    const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * kBM + kBM + coff)) : Sk;   // (coff < 0: the first -coff queries see no key)
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
-    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? min(Sk, q0w + 32 + coff) : Sk);
+    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
     auto load_q = [&](int qblk) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
     const int NT = my_nt;                          // 64-key tiles this wave computes on
-    const int mb = min(CAUSAL ? ((q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block whose softmax needs the mask
+    const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block whose softmax needs the mask
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
     int j = 0;
     if (NT > 0) {

@@ -278,7 +278,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     """Fused attention forward on MI355X.  ``q, k, v``: (B, H, N, D) GPU tensors; ``k, v`` may have fewer heads
     (B, H_kv, N_k, D) with H % H_kv == 0 (grouped-query / multi-query attention; dk, dv then have H_kv heads too) and a
     length N_k of their own; with ``causal`` the mask is then bottom-right aligned (key j visible to query i iff
-    j <= i + N_k - N) and needs N_k >= N.
+    j <= i + N_k - N); for N_k < N the first N - N_k queries see no key (their output rows are 0, their LSE -inf).
 
     Returns O with q's dtype (fp32 inputs are computed in fp16 and cast back, like the
     reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural

@@ -144,7 +144,8 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
  *          key/value head h / (H / H_kv) (grouped-query / multi-query attention: consecutive query heads share one).
  *   S_k  : Q, O, dO, dQ, LSE have S_q rows, K, V, dK, dV have S_k rows (S_k >= 1).  The causal mask is then
  *          bottom-right aligned -- key j is visible to query i iff j <= i + S_k - S_q (the last query sees every key:
- *          chunked prefill / decoding against a longer key/value history) -- and needs S_k >= S_q.
+ *          chunked prefill / decoding against a longer key/value history).  For S_k < S_q the first S_q - S_k queries
+ *          see no key: their O rows are 0, their LSE -inf, and they contribute no gradient.
  * Everything else is as in the entry point of the same name; the strides of K, V, dK, dV address [B, H_kv, S_k, D]
  * tensors (NULL = contiguous).  dK and dV are the sums over the query heads of the group, accumulated in registers by
  * one workgroup per (key block, key/value head): still no atomics, no zero-fill, bitwise deterministic.

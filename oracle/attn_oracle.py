@@ -92,7 +92,9 @@ def sdpa_oracle(q, k, v, causal: bool = False, scale: float | None = None):
 def naive_attention_f64(q, k, v, causal: bool = False, scale: float | None = None):
     """q,k,v: numpy (B,H,N,D) any float dtype. Returns (o f64, lse f64).
     k, v may have another length N_k (not a reference case: its q, k, v share one N); the causal mask is then
-    bottom-right aligned, key j visible to query i iff j <= i + N_k - N (for N_k == N the reference's rule)."""
+    bottom-right aligned, key j visible to query i iff j <= i + N_k - N (for N_k == N the reference's rule); for
+    N_k < N the first N - N_k queries see no key: their output is 0 and their LSE -inf (the l == 0 guard of
+    flash_attn_cutlass.cu:446-452)."""
     q = np.asarray(q, dtype=np.float64)
     k = np.asarray(k, dtype=np.float64)
     v = np.asarray(v, dtype=np.float64)
@@ -106,10 +108,12 @@ def naive_attention_f64(q, k, v, causal: bool = False, scale: float | None = Non
         j = np.arange(Nk)[None, :]
         s = np.where(j > i + (Nk - N), -np.inf, s)       # FA2-triton.py:70-73
     m = s.max(axis=-1, keepdims=True)                    # :588-592
+    m = np.where(np.isneginf(m), 0.0, m)                 # a query that sees no key (only possible for N_k < N, causal)
     p = np.exp(s - m)                                    # pass 2 :594-600
     l = p.sum(axis=-1, keepdims=True)
-    o = np.einsum("bhij,bhjd->bhid", p, v) / l           # pass 3 :602-613
-    lse = (m + np.log(l))[..., 0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        o = np.where(l > 0, np.einsum("bhij,bhjd->bhid", p, v) / l, 0.0)   # pass 3 :602-613; l == 0 -> 0 (flash_attn_cutlass.cu:446-452)
+        lse = np.where(l > 0, m + np.log(l), -np.inf)[..., 0]
     return o, lse
 
 
@@ -203,8 +207,11 @@ def naive_attention_bwd_f64(q, k, v, do, causal: bool = False, scale: float | No
         j = np.arange(Nk)[None, :]
         s = np.where(j > i + (Nk - N), -np.inf, s)                   # :148-151
     m = s.max(axis=-1, keepdims=True)
+    m = np.where(np.isneginf(m), 0.0, m)                             # a query that sees no key: P = 0, no gradient
     p = np.exp(s - m)
-    p /= p.sum(axis=-1, keepdims=True)                               # :156 (exp(qk-m)/l)
+    l = p.sum(axis=-1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p = np.where(l > 0, p / l, 0.0)                              # :156 (exp(qk-m)/l)
     dv = np.einsum("bhij,bhid->bhjd", p, do)                         # :158
     dp = np.einsum("bhid,bhjd->bhij", do, v)                         # :159
     delta = (dp * p).sum(axis=-1, keepdims=True)                     # :160

@@ -111,3 +111,20 @@ def test_oracle_other_key_length_is_the_tail_of_the_square_problem():
     s = np.einsum("bhid,bhjd->bhij", q, k) / np.sqrt(D)
     p = np.exp(s - s.max(-1, keepdims=True))
     assert np.allclose(o_nc, np.einsum("bhij,bhjd->bhid", p / p.sum(-1, keepdims=True), v), atol=1e-14)
+
+
+def test_oracle_queries_without_keys_give_zero():
+    """N_k < N under the bottom-right aligned causal mask: the first N - N_k queries see no key -> O = 0, LSE = -inf,
+    dq = 0 (the l == 0 guard of flash_attn_cutlass.cu:446-452); the remaining queries are the square N_k problem."""
+    rng = np.random.default_rng(3)
+    B, H, N, Nk, D = 1, 1, 50, 20, 16
+    q, do = rng.standard_normal((B, H, N, D)), rng.standard_normal((B, H, N, D))
+    k, v = rng.standard_normal((B, H, Nk, D)), rng.standard_normal((B, H, Nk, D))
+    o, lse = orc.naive_attention_f64(q, k, v, causal=True)
+    assert (o[:, :, :N - Nk] == 0).all() and np.isneginf(lse[:, :, :N - Nk]).all()
+    o_sq, lse_sq = orc.naive_attention_f64(q[:, :, N - Nk:], k, v, causal=True)
+    assert np.array_equal(o[:, :, N - Nk:], o_sq) and np.array_equal(lse[:, :, N - Nk:], lse_sq)
+    dq, dk, dv, _ = orc.naive_attention_bwd_f64(q, k, v, do, causal=True)
+    dq_sq, dk_sq, dv_sq, _ = orc.naive_attention_bwd_f64(q[:, :, N - Nk:], k, v, do[:, :, N - Nk:], causal=True)
+    assert (dq[:, :, :N - Nk] == 0).all() and np.allclose(dq[:, :, N - Nk:], dq_sq, atol=1e-14)
+    assert np.allclose(dk, dk_sq, atol=1e-13) and np.allclose(dv, dv_sq, atol=1e-13)
