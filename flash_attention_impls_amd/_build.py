@@ -5,6 +5,8 @@ The product is one C-ABI shared object, ``flash_attention_impls_amd/libfa_mi355.
 """
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -32,24 +34,57 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+DIGEST_PATH = LIB_PATH + ".digest"      # sha256 of the sources and flags the library was built from (travels with it)
+
+
+def sources_digest() -> str:
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for d in DEPS:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
+    """True if the library is missing or was built from other sources.  Decided by content (a digest written next to the
+    library), not by modification times: a copy of the tree to another machine may reorder those, and N ranks
+    starting together must not all decide to rebuild."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+    try:
+        with open(DIGEST_PATH) as f:
+            return f.read().strip() != sources_digest()
+    except OSError:
+        t = os.path.getmtime(LIB_PATH)       # no digest (library built by hand): fall back to modification times
+        return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the library if missing or older than its sources; returns its path."""
+    """Compile the library if missing or built from other sources; returns its path.  Safe to call from several
+    processes at once: one builds (file lock, private temporary, atomic rename), the others wait and find it done."""
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [hipcc_path(), *HIPCC_FLAGS, "-o", LIB_PATH + ".tmp", *SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():          # built by another process while this one waited
+                return LIB_PATH
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = [hipcc_path(), *HIPCC_FLAGS, "-o", tmp, *SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp, LIB_PATH)
+            with open(DIGEST_PATH + ".tmp", "w") as f:
+                f.write(sources_digest() + "\n")
+            os.replace(DIGEST_PATH + ".tmp", DIGEST_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

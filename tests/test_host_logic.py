@@ -259,3 +259,39 @@ def test_grouped_query_entry_points_validate_without_gpu():
         fa.check_args(q, torch.zeros(1, 4, 8, 64), torch.zeros(1, 4, 8, 64))
     with pytest.raises(fa.FlashAttnArgumentError, match="identical shapes"):
         fa.check_args(q, k, torch.zeros(1, 3, 8, 64))
+
+
+def test_concurrent_builds_compile_once_and_staleness_is_by_content(tmp_path):
+    """N ranks importing the package together (bench.py under torch.distributed.run) must not race on the library:
+    staleness is decided by a digest of the sources (not by modification times, which a copy of the tree may reorder),
+    one process compiles behind a file lock and the others find it done.  Uses a stand-in compiler that copies the
+    existing library, so nothing is really rebuilt."""
+    import shutil
+    import subprocess
+    import sys
+    from flash_attention_impls_amd import _build
+    fa.load_library()                                            # make sure the real library and its digest exist
+    assert not _build.is_stale()
+    real = tmp_path / "real.so"
+    shutil.copy(_build.LIB_PATH, real)
+    log = tmp_path / "calls.log"
+    fake = tmp_path / "fake_hipcc"
+    fake.write_text("#!/bin/sh\necho call >> %s\nsleep 1\nwhile [ $# -gt 0 ]; do if [ \"$1\" = -o ]; then out=$2; fi; shift; done\n"
+                    "cp %s \"$out\"\n" % (log, real))
+    fake.chmod(0o755)
+    # modification times do not matter ...
+    os.utime(_build.DEPS[0])
+    assert not _build.is_stale()
+    # ... the recorded digest does
+    with open(_build.DIGEST_PATH, "w") as f:
+        f.write("stale\n")
+    assert _build.is_stale()
+    env = dict(os.environ, HIPCC=str(fake))
+    code = "from flash_attention_impls_amd import _build; _build.build()"
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, cwd=os.path.dirname(_build.PKG_DIR),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(4)]
+    errs = [p.communicate()[1].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), errs
+    assert log.read_text().count("call") == 1                    # one compile for four processes
+    assert not _build.is_stale()
+    assert fa.load_library(_build.LIB_PATH).fa_version() == 120
