@@ -1,7 +1,7 @@
-"""Python host side of the MI355X FlashAttention forward: the reference's operator entry
+"""Python host side of the MI355X FlashAttention (forward and backward): the reference's operator entry
 point re-implemented over the C-ABI HIP library (``include/fa_mi355.h``).
 
-Mirrors, for the forward path only:
+Mirrors:
   * ``flash_attention(q, k, v, causal=False)``   code/triton_fa2/FA2-triton.py:240-244
     (positional (B,H,N,D) tensors; fp32 inputs are computed in fp16 and cast back :241-244)
   * ``_FlashAttnFn.forward``                      code/triton_fa2/FA2-triton.py:175-205
