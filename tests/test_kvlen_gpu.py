@@ -135,3 +135,24 @@ def test_other_key_length_errors():
     fa.flash_attn(q, k, k, causal=False)
     with pytest.raises(fa.FlashAttnArgumentError):
         fa.flash_attn(q, k[:, :, :0], k[:, :, :0])               # no keys
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("D", [128, 64])
+def test_exact_fallback_with_grouped_heads_and_other_key_length(causal, D):
+    """A score spike beyond the fixed softmax reference's range sends the workgroup through the exact online-softmax
+    fallback; here with grouped key/value heads and S_k != S_q (the fallback has its own tile ranges and mask)."""
+    B, H, Hkv, Sq, Sk = 1, 4, 2, 384, 900
+    q, k, v, _ = rand(B, H, Hkv, Sq, Sk, D, torch.bfloat16, seed=21 + D)
+    q = q * 0.25
+    k[0, 0, 700] = (q[0, 1, 300] * 160.0).to(torch.bfloat16)      # key/value head 0 serves query heads 0, 1
+    k[0, 1, 133] = (q[0, 2, 20] * 160.0).to(torch.bfloat16)
+    o, lse = fa.flash_attn(q, k, v, causal, return_lse=True)
+    G = H // Hkv
+    qn, kn, vn = [t.float().cpu().numpy() for t in (q, k.repeat_interleave(G, 1), v.repeat_interleave(G, 1))]
+    ref, lse_ref = orc.naive_attention_f64(qn, kn, vn, causal=causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert np.abs(o.float().cpu().numpy() - ref).max() <= TOL["bf16"] * max(1.0, np.abs(ref).max())
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+    s = float(q[0, 1, 300].float() @ k[0, 0, 700].float()) / np.sqrt(D) * 1.4427
+    assert s > 70                                                  # really beyond the fast path's range
