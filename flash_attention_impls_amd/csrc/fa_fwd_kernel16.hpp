@@ -54,6 +54,11 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     static_assert(D == 128 || (D == 64 && !QK8), "head_dim 64 has no fp8 Q/K variant");
     constexpr int NG = D / 64;                 // groups of four head_dim tiles in the P V product
     constexpr int NWAVES = 8;
+#if defined(FA_DMA_SPREAD) && FA_DMA_SPREAD == 0
+    constexpr bool SPREAD = false;
+#else
+    constexpr bool SPREAD = DD == 128;         // (see FA_SYNC_STAGE below)
+#endif
     constexpr int QKB = QK8 ? 1 : 2;           // bytes per Q / K element
     constexpr int KROWB = D * QKB;             // bytes per K row in LDS
     constexpr int CPTK = kBN * KROWB / 1024 / NWAVES;   // K DMA pieces per wave per tile (2, fp8: 1)
@@ -174,6 +179,16 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         for (int i = 0; i < CPT; ++i)
             dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + stage_off + i * PIECE), (unsigned)j * v_tile_stride + g_voff[i]);
     };
+    // piece I of the K(j + 3), V(j + 2) staging that follows barrier j (K pieces first); stage_j = ring stage of tile j
+    auto dma_piece = [&] __device__ (auto i_c, int j, int stage_j) {
+        constexpr int I = decltype(i_c)::value;
+        if constexpr (I < CPTK)
+            dma16(rk_w, __builtin_amdgcn_readfirstlane(kpiece_base + ((stage_j + 3) & (kStages - 1)) * TILE + I * PIECE),
+                  (unsigned)(j + 3) * k_tile_stride + g_koff[I]);
+        else if constexpr (I < CPTK + CPT)
+            dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + ((stage_j + 2) & (kStages - 1)) * TILE + (I - CPTK) * PIECE),
+                  (unsigned)(j + 2) * v_tile_stride + g_voff[I - CPTK]);
+    };
 
     // ---- LDS read addresses (they carry the ring-stage offset of the tile currently being read)
     // K fragment: lane (li,lg) reads K[half*32 + 16 kt + li][32 ks + 8 lg + 0..7] = chunk 4 ks + lg of the row
@@ -202,6 +217,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     auto read_kgroup = [&] __device__ (auto stage_c, auto half_c, auto kt_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, kt = decltype(kt_c)::value;
         constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half + 16 * kt) * KROWB;
+#if defined(FA_ABL_NOLDS)          // timing-only ablation builds (wrong results; tools/ab_bench.py): no fragment reads
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (QK8) kf8[ks] = lds_read_b64(ka[ks] + off);
@@ -211,6 +229,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     auto read_vgroup = [&] __device__ (auto stage_c, auto half_c, auto grp_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, grp = decltype(grp_c)::value;
         constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half) * ROWB;
+#if defined(FA_ABL_NOLDS)
+        return;
+#endif
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + off);
@@ -244,10 +265,20 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
                 if ((key >= Sk) || (CAUSAL && key > qrow + coff)) sv[e] = -INFINITY;
             }
         }
+#if defined(FA_ABL_NOVALU)         // no softmax arithmetic at all: the raw accumulator words stand in for P
+        pf[par][qt][2 * kt] = bitcast<unsigned>(sv[0]);
+        pf[par][qt][2 * kt + 1] = bitcast<unsigned>(sv[2]);
+        return;
+#endif
+#if defined(FA_ABL_NOEXP)          // everything but the exponentials
+        const float p0 = __builtin_fmaf(sv[0], c, -m_c[qt]), p1 = __builtin_fmaf(sv[1], c, -m_c[qt]);
+        const float p2 = __builtin_fmaf(sv[2], c, -m_c[qt]), p3 = __builtin_fmaf(sv[3], c, -m_c[qt]);
+#else
         const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[0], c, -m_c[qt]));
         const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[1], c, -m_c[qt]));
         const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[2], c, -m_c[qt]));
         const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[3], c, -m_c[qt]));
+#endif
         l_a[qt] += p0; l_b[qt] += p1; l_a[qt] += p2; l_b[qt] += p3;
         pf[par][qt][2 * kt] = T::pack2(p0, p1);
         pf[par][qt][2 * kt + 1] = T::pack2(p2, p3);
@@ -312,7 +343,11 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     // One pipeline block n (HALF = n & 1): MFMA  PV(n-2) | S(n);  VALU softmax(n-1);  four fenced regions of
     // 8 MFMAs + one softmax slice + one fragment-group read each (see fa_fwd_kernel.hpp for the protocol).
-    auto block = [&] __device__ (auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, auto st_c, int n, int dk, int dv) {
+    int stage_k = 0;                               // ring stage of tile j
+    // DMA = true (odd blocks only): the four staging pieces that follow this iteration's barrier are issued one per
+    // region boundary instead of back to back behind the barrier
+    auto block_d = [&] __device__ (auto dma_c, auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, auto st_c, int n, int dk, int dv) {
+        constexpr bool DMA = decltype(dma_c)::value;
         constexpr int ST = decltype(st_c)::value;            // ring stage of K tile n >> 1, or -1 (runtime addresses)
         typedef IC<ST> SK;                                   // K(j) stage
         typedef IC<(ST < 0 ? -1 : ((ST + 3) & 3))> SV;      // V(j-1) stage
@@ -363,7 +398,27 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             }
 #endif
         };
+        auto spread = [&] __device__ (auto r_c) {
+            constexpr int R = decltype(r_c)::value;                  // region about to start
+            if constexpr (DMA) {
+#if FA_DMA_SPREAD == 2          // two pieces in front of each S region
+                if constexpr (R == 1 || R == 3) {
+                    dma_piece(IC<R - 1>{}, n >> 1, ST < 0 ? stage_k : ST);
+                    dma_piece(IC<R>{}, n >> 1, ST < 0 ? stage_k : ST);
+                }
+#elif FA_DMA_SPREAD == 1        // one piece per region
+                dma_piece(r_c, n >> 1, ST < 0 ? stage_k : ST);
+#else                           // two pieces in front of each PV region (measured: the three placements are within noise)
+                if constexpr (R == 0 || R == 2) {
+                    dma_piece(IC<R>{}, n >> 1, ST < 0 ? stage_k : ST);
+                    dma_piece(IC<R + 1>{}, n >> 1, ST < 0 ? stage_k : ST);
+                }
+#endif
+            }
+        };
         // ---- region 0: PV, head_dim tiles 0..3 | softmax slice (kt 0, qt 0)
+        __builtin_amdgcn_sched_barrier(0);
+        spread(IC<0>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DO_PV) {
             mfma_pv(P_PV{}, IC<0>{});
@@ -375,6 +430,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         }
         hint(IC<8>{}, IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
+        spread(IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
         // ---- region 1: S, key tile 0 | slice (kt 0, qt 1)
         if constexpr (DO_S) {
             mfma_s(IC<HALF>{}, IC<0>{});
@@ -382,6 +439,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         }
         if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<0>{}, IC<1>{}, key0);
         hint(IC<4>{}, IC<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        spread(IC<2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 2: PV, head_dim tiles 4..7 | slice (kt 1, qt 0)
         if constexpr (DO_PV && NG == 2) mfma_pv(P_PV{}, IC<1>{});
@@ -391,6 +450,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         read_vgroup(SVn{}, IC<HALF ^ 1>{}, IC<0>{});          // next block's first V^T fragments
         if constexpr (DO_SM) sm_slice(mask_c, P_SM{}, IC<1>{}, IC<0>{}, key0);
         hint(IC<8>{}, IC<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        spread(IC<3>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- region 3: S, key tile 1 | slice (kt 1, qt 1)
         if constexpr (DO_S) mfma_s(IC<HALF>{}, IC<1>{});
@@ -402,6 +463,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     typedef std::true_type Y;
     typedef std::false_type N;
+    auto block = [&] __device__ (auto... args) { block_d(N{}, args...); };
+    auto block_s = [&] __device__ (auto... args) { block_d(Y{}, args...); };     // odd block behind a sync_only()
     typedef std::integral_constant<int, 0> half0_t;
     typedef std::integral_constant<int, 1> half1_t;
 
@@ -417,30 +480,49 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     dma_wait<2 * CPTK + CPT>(); // this wave's pieces of K(0), V(0) have landed ...
     __syncthreads();            // ... and every wave's are visible
 
-    int stage_k = 0;                               // ring stage of tile j
     int dk = 0, dv = 0;                            // address deltas used by the odd block of iteration j
     auto begin_iter = [&](int j) {
         dk = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;          // K(j) -> K(j+1)
         dv = (j == 0) ? 0 : ((stage_k == 0) ? -(kStages - 1) * TILE : TILE);   // V(j-1) -> V(j)
     };
     auto sync_and_stage = [&](int j) {             // barrier(j) + DMA of K(j+3), V(j+2)
+#if !defined(FA_ABL_NOBARRIER)
         dma_wait<CPTK + CPT>();                    // everything but the previous iteration's DMA has landed ...
         __syncthreads();                           // ... and is published; last iteration's reads are done
+#endif
+#if !defined(FA_ABL_NODMA)
         dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
         dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+#endif
     };
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
-    auto sync_and_stage_c = [&] __device__ (auto st_c, int j) {      // same, ring stage of tile j known at compile time
-        constexpr int ST = decltype(st_c)::value;
+    auto sync_only = [&]() {                       // barrier(j) alone: the odd block that follows issues the DMAs
+#if !defined(FA_ABL_NOBARRIER)
         dma_wait<CPTK + CPT>();
         __syncthreads();
+#endif
+    };
+    auto sync_and_stage_c = [&] __device__ (auto st_c, int j) {      // same, ring stage of tile j known at compile time
+        constexpr int ST = decltype(st_c)::value;
+#if !defined(FA_ABL_NOBARRIER)
+        dma_wait<CPTK + CPT>();
+        __syncthreads();
+#endif
+#if !defined(FA_ABL_NODMA)
         dma_k(j + 3, ((ST + 3) & (kStages - 1)) * TILE);
         dma_v(j + 2, ((ST + 2) & (kStages - 1)) * TILE);
+#endif
     };
 
 #if defined(FA_PRIO)
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
+    // head_dim 128: the staging DMAs of an iteration are not issued back to back behind its barrier (where all eight
+    // waves would queue them at once) but ride on region boundaries of its odd block: +1.3 ... 2 % (FA_DMA_SPREAD=0
+    // restores the old placement; at head_dim 64, two workgroups per CU within 128 registers, it costs 7 %)
+#define FA_SYNC_STAGE(j) do { if constexpr (SPREAD) sync_only(); else sync_and_stage(j); } while (0)
+#define FA_SYNC_STAGE_C(st, j) do { if constexpr (SPREAD) sync_only(); else sync_and_stage_c(st, j); } while (0)
+#define FA_ODD_BLOCK(...) do { if constexpr (SPREAD) block_s(__VA_ARGS__); else block(__VA_ARGS__); } while (0)
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block whose softmax needs the mask
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
@@ -449,8 +531,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         read_kgroup(IC<-1>{}, IC<0>{}, IC<0>{});
         begin_iter(0);                             // iteration 0 (pipeline fill); softmax(0) fixes the reference
         block(half0_t{}, Y{}, N{}, N{}, N{}, N{}, IC<-1>{}, 0, 0, 0);
-        sync_and_stage(0);
-        block(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, IC<-1>{}, 1, dk, dv);
+        FA_SYNC_STAGE(0);
+        FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, IC<-1>{}, 1, dk, dv);
         end_iter();
         j = 1;
         const int ja = min(jm, NT);
@@ -464,17 +546,17 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             for (int dt = 0; dt < DT; ++dt) va[dt] -= sv0;
             for (; j + 4 <= ja; j += 4) {
                 block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j, 0, 0);
-                sync_and_stage_c(IC<1>{}, j);
-                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j + 1, 0, 0);
+                FA_SYNC_STAGE_C(IC<1>{}, j);
+                FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j + 1, 0, 0);
                 block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<2>{}, 2 * j + 2, 0, 0);
-                sync_and_stage_c(IC<2>{}, j + 1);
-                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<2>{}, 2 * j + 3, 0, 0);
+                FA_SYNC_STAGE_C(IC<2>{}, j + 1);
+                FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<2>{}, 2 * j + 3, 0, 0);
                 block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<3>{}, 2 * j + 4, 0, 0);
-                sync_and_stage_c(IC<3>{}, j + 2);
-                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<3>{}, 2 * j + 5, 0, 0);
+                FA_SYNC_STAGE_C(IC<3>{}, j + 2);
+                FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<3>{}, 2 * j + 5, 0, 0);
                 block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<0>{}, 2 * j + 6, 0, 0);
-                sync_and_stage_c(IC<0>{}, j + 3);
-                block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<0>{}, 2 * j + 7, 0, 0);
+                FA_SYNC_STAGE_C(IC<0>{}, j + 3);
+                FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<0>{}, 2 * j + 7, 0, 0);
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) ka[ks] += sk0;           // back to stage-carrying addresses (stage_k unchanged)
@@ -484,15 +566,15 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         for (; j < ja; ++j) {                      // steady state, no masking
             begin_iter(j);
             block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j, 0, 0);
-            sync_and_stage(j);
-            block(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
+            FA_SYNC_STAGE(j);
+            FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
             end_iter();
         }
         for (; j < NT; ++j) {                      // steady state with masking (diagonal / ragged tiles)
             begin_iter(j);
             block(half0_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j, 0, 0);
-            sync_and_stage(j);
-            block(half1_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
+            FA_SYNC_STAGE(j);
+            FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
             end_iter();
         }
         begin_iter(j);                             // iteration NT (pipeline drain)
@@ -502,6 +584,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         end_iter();
         ++j;
     }
+#undef FA_SYNC_STAGE
+#undef FA_SYNC_STAGE_C
+#undef FA_ODD_BLOCK
     for (; j < nt; ++j) {                          // remaining tiles of the workgroup: staging duty only
         sync_and_stage(j);
         end_iter();
