@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOL, c_oracle_fwd, golden_f32, golden_names, golden_torch, load_golden
+from conftest import TOL, c_oracle_fwd, golden_names, golden_torch, load_golden
 from oracle import attn_oracle as orc
 
 pytestmark = pytest.mark.gpu

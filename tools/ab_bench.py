@@ -3,7 +3,6 @@
   python tools/ab_bench.py build/libA.so build/libB.so ... [--causal 1] [--rounds 5]
 """
 import argparse
-import ctypes
 import os
 import sys
 

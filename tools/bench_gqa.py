@@ -15,7 +15,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flash_attention_impls_amd as fa  # noqa: E402
-from flash_attention_impls_amd import flash_attn as host  # noqa: E402,F401
 import importlib  # noqa: E402
 
 hostmod = importlib.import_module("flash_attention_impls_amd.flash_attn")

@@ -5,7 +5,6 @@ import math
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 
