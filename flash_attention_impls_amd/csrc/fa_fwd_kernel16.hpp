@@ -487,7 +487,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     };
     auto sync_and_stage = [&](int j) {             // barrier(j) + DMA of K(j+3), V(j+2)
 #if !defined(FA_ABL_NOBARRIER)
+#if !defined(FA_ABL_NOVMWAIT)      // timing-only: the barrier without the wait for the staged tile
         dma_wait<CPTK + CPT>();                    // everything but the previous iteration's DMA has landed ...
+#endif
         __syncthreads();                           // ... and is published; last iteration's reads are done
 #endif
 #if !defined(FA_ABL_NODMA)
@@ -498,14 +500,18 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
     auto sync_only = [&]() {                       // barrier(j) alone: the odd block that follows issues the DMAs
 #if !defined(FA_ABL_NOBARRIER)
+#if !defined(FA_ABL_NOVMWAIT)      // timing-only: the barrier without the wait for the staged tile
         dma_wait<CPTK + CPT>();
+#endif
         __syncthreads();
 #endif
     };
     auto sync_and_stage_c = [&] __device__ (auto st_c, int j) {      // same, ring stage of tile j known at compile time
         constexpr int ST = decltype(st_c)::value;
 #if !defined(FA_ABL_NOBARRIER)
+#if !defined(FA_ABL_NOVMWAIT)      // timing-only: the barrier without the wait for the staged tile
         dma_wait<CPTK + CPT>();
+#endif
         __syncthreads();
 #endif
 #if !defined(FA_ABL_NODMA)
