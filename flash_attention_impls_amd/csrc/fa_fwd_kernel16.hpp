@@ -217,9 +217,6 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     auto read_kgroup = [&] __device__ (auto stage_c, auto half_c, auto kt_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, kt = decltype(kt_c)::value;
         constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half + 16 * kt) * KROWB;
-#if defined(FA_ABL_NOLDS)          // timing-only ablation builds (wrong results; tools/ab_bench.py): no fragment reads
-        return;
-#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (QK8) kf8[ks] = lds_read_b64(ka[ks] + off);
@@ -229,9 +226,6 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     auto read_vgroup = [&] __device__ (auto stage_c, auto half_c, auto grp_c) {
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, grp = decltype(grp_c)::value;
         constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half) * ROWB;
-#if defined(FA_ABL_NOLDS)
-        return;
-#endif
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + off);
@@ -265,7 +259,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
                 if ((key >= Sk) || (CAUSAL && key > qrow + coff)) sv[e] = -INFINITY;
             }
         }
-#if defined(FA_ABL_NOVALU)         // no softmax arithmetic at all: the raw accumulator words stand in for P
+#if defined(FA_ABL_NOVALU)         // timing-only ablation builds (wrong results; tools/ab_bench.py). No softmax arithmetic at all: the raw accumulator words stand in for P
         pf[par][qt][2 * kt] = bitcast<unsigned>(sv[0]);
         pf[par][qt][2 * kt + 1] = bitcast<unsigned>(sv[2]);
         return;
