@@ -96,19 +96,21 @@ int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
 }
 
 // fp8 (OCP e4m3fn) -> bf16, exact (every e4m3 value is representable in bf16).  HBM-bound streaming pass:
-// blockIdx.y = (batch, head) slice, a thread converts 16 bytes of one sequence row per step (16-byte loads,
-// 2 x 16-byte stores); rows are D contiguous bytes addressed through the source strides, written contiguously.
+// `bx` consecutive blocks per (batch, head) slice (flattened grid: no 65535 limit on B*H), a thread converts 16 bytes
+// of one sequence row per step (16-byte loads, 2 x 16-byte stores); rows are D contiguous bytes addressed through the
+// source strides, written contiguously.
 typedef __attribute__((ext_vector_type(2))) float cvt_f32x2;
 __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* __restrict__ src, unsigned short* __restrict__ dst,
-                                                           int D, int H, int S, long long sb, long long sh, long long ss)
+                                                           int D, int H, int S, int bx, long long sb, long long sh, long long ss)
 {
-    const int bh = blockIdx.y;
+    const int bh = blockIdx.x / bx;
+    const int blk = blockIdx.x - bh * bx;
     const int b = bh / H, h = bh - b * H;
     const unsigned char* sp = src + b * sb + h * sh;
     unsigned short* dp = dst + (long long)bh * S * D;
     const int cpr = D / 16;                                   // 16-byte chunks per row (8 or 4)
     const int total = S * cpr;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    for (int t = blk * blockDim.x + threadIdx.x; t < total; t += bx * blockDim.x) {
         const int row = t / cpr, ch = t - row * cpr;
         const fa::u32x4 in = *reinterpret_cast<const fa::u32x4*>(sp + (long long)row * ss + ch * 16);
         fa::u32x4 out[2];
@@ -297,17 +299,18 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
         if (st[t][0] % 16 || st[t][1] % 16 || st[t][2] % 16 || reinterpret_cast<uintptr_t>(src[t]) % 16)
             return fail(FA_ERR_BAD_STRIDE, "fp8 tensors need 16-byte aligned rows");
     }
-    if ((long long)B * H > 65535) return fail(FA_ERR_TOO_LARGE, "B*H > 65535 not supported by the fp8 pre-pass");
     char* w = static_cast<char*>(workspace);
     char* wt[3] = {w, w + one_q, w + one_q + one_kv};   // the workspace holds the converted tensors back to back
     if (native_qk) wt[2] = w;
     for (int t = native_qk ? 2 : 0; t < 3; ++t) {
         const int per_slice = rows[t] * (D / 16);
         const int bx = std::max(1, std::min((per_slice + 255) / 256, 64));
-        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3(bx, B * heads[t]), dim3(256), 0, s,
+        const long long blocks = (long long)bx * B * heads[t];
+        if (blocks > 0x7FFFFFFFll) return fail(FA_ERR_TOO_LARGE, "fp8 pre-pass grid too large");
+        hipLaunchKernelGGL(fp8_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                            reinterpret_cast<const unsigned char*>(src[t]),
                            reinterpret_cast<unsigned short*>(wt[t]),
-                           D, heads[t], rows[t], st[t][0], st[t][1], st[t][2]);
+                           D, heads[t], rows[t], bx, st[t][0], st[t][1], st[t][2]);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fp8 conversion launch failed: %s", hipGetErrorString(e));
     }

@@ -530,3 +530,16 @@ def test_fp8_native_qk_matches_convert_all_build(tmp_path):
             assert (o0.float() - o1.float()).abs().max() <= 2 ** -6
     finally:
         fa_mod._lib_handle = default
+
+
+def test_fp8_more_than_65535_heads():
+    """B*H beyond the 65535 limit of a grid's y dimension: the fp8 pre-pass runs on a flattened grid."""
+    B, H, S, D = 1100, 64, 16, 128                    # 70400 (batch, head) slices
+    g = torch.Generator().manual_seed(2)
+    q, k, v = [torch.randn(B, H, S, D, generator=g).to(torch.float8_e4m3fn).cuda() for _ in range(3)]
+    o = fa.flash_attn(q, k, v, True)
+    idx = [0, 1, 65535, 65536, B * H - 1]
+    qs, ks, vs = [t.view(B * H, S, D)[idx].float() for t in (q, k, v)]
+    ref = torch.nn.functional.scaled_dot_product_attention(qs, ks, vs, is_causal=True)
+    got = o.view(B * H, S, D)[idx].float()
+    assert ((got - ref).norm() / ref.norm()).item() < 5e-2
