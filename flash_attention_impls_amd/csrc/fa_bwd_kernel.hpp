@@ -53,6 +53,7 @@ struct BwdParams {
     int Spad;                           // S rounded up to a multiple of 64
     int bh;                             // B*H
     int nxb;                            // stationary blocks per head
+    int unpaired;                       // MODE 0, causal: 1 = one query block per workgroup (small grids), 0 = block pairs
     long long x1_sb, x1_sh, x1_ss;      // element strides (head_dim stride is 1)
     long long x2_sb, x2_sh, x2_ss;
     long long y1_sb, y1_sh, y1_ss;
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     // MODE 0 under the causal mask: a workgroup takes the query-block pair (nxb-1-t, t), so that every workgroup
     // streams nxb+1 blocks' worth of tiles (a balanced grid, as in the forward); MODE 1 launches the heaviest key
     // blocks (the first ones) first
-    constexpr bool PAIR = MODE == 0 && CAUSAL;
+    constexpr bool PAIRABLE = MODE == 0 && CAUSAL;
+    const bool PAIR = PAIRABLE && !p.unpaired;
     const int wg_per_head = PAIR ? (p.nxb + 1) / 2 : p.nxb;
     const int hl = slot / wg_per_head;
     const int t = slot - hl * wg_per_head;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     const int coff = (CAUSAL && MODE == 0) ? p.coff : 0;      // (MODE 1 is launched for equal lengths only)
     const int n_pass = (PAIR && p.nxb - 1 - t != t) ? 2 : 1;
   for (int pass = 0; pass < n_pass; ++pass) {
-    const int xb = PAIR ? (pass == 0 ? p.nxb - 1 - t : t) : t;
+    const int xb = PAIRABLE ? (pass == 0 ? p.nxb - 1 - t : t) : t;      // (unpaired: one pass, longest blocks first)
     const int x0 = xb * XB;                    // first stationary row of the workgroup
     asm volatile("" : "+v"(lane));             // per-pass opaque lane id: nothing derived from it is hoisted out of the pass loop
     const int li = lane & 15;

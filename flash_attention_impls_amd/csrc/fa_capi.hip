@@ -127,11 +127,20 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
     }
 }
 
+// causal launches pair query blocks (nqb-1-t, t) per workgroup for equal work -- unless every query block can have one
+// of the 256 CUs to itself: then the longest block alone sets the time, one block less than a pair
+bool unpaired_for(int B, int H, int S, bool causal)
+{
+    const long long heads = (((long long)B * H + 7) / 8) * 8;
+    const long long nqb = (S + fa::kBM - 1) / fa::kBM;
+    return causal && nqb > 1 && heads * nqb <= 256;
+}
+
 int grid_for(int B, int H, int S, bool causal)
 {
     const long long bh = (long long)B * H;
     const long long nqb = (S + fa::kBM - 1) / fa::kBM;
-    const long long per_head = causal ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
+    const long long per_head = (causal && !unpaired_for(B, H, S, causal)) ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
     const long long g = ((bh + 7) / 8) * 8 * per_head;         // heads padded to a multiple of 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
 }
@@ -202,6 +211,7 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.G = H / H_kv;
     p.dv = D;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
+    p.unpaired = unpaired_for(B, H, S, causal != 0) ? 1 : 0;
     p.bh = B * H;
     if (!set_strides(q_strides, H, S, D, p.q_sb, p.q_sh, p.q_ss) ||
         !set_strides(k_strides, H_kv, S_k, D, p.k_sb, p.k_sh, p.k_ss) ||
@@ -325,6 +335,7 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     p.B = B; p.H = H; p.S = S; p.Sk = S_k; p.dv = D;
     p.G = H / H_kv;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
+    p.unpaired = unpaired_for(B, H, S, causal != 0) ? 1 : 0;
     p.bh = B * H;
     p.q_sb = st[0][0]; p.q_sh = st[0][1]; p.q_ss = st[0][2];
     p.k_sb = st[1][0]; p.k_sh = st[1][1]; p.k_ss = st[1][2];

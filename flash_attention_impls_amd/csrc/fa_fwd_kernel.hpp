@@ -51,6 +51,7 @@ struct FwdParams {
     int dv;                  // valid head_dim (a multiple of 16, <= the kernel's compiled D): columns dv .. D-1 of every
                              // Q / K / V row are read as zeros (buffer offsets pushed out of range) and not stored in O
     int nqb;                 // ceil(S / 256)
+    int unpaired;            // causal launches only: 1 = one query block per workgroup (small grids), 0 = block pairs
     int bh;                  // B*H
     // element strides (innermost head_dim stride is 1)
     long long q_sb, q_sh, q_ss;
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int wg_per_head = CAUSAL ? (p.nqb + 1) / 2 : p.nqb;
+    // causal: a workgroup takes the query-block pair (nqb-1-t, t) -- equal work for every workgroup -- unless the launch is
+    // so small that every query block can have a CU of its own (p.unpaired: then the longest block alone sets the time)
+    const bool paired = CAUSAL && !p.unpaired;
+    const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
     const int hl = slot / wg_per_head;
     const int tq = slot - hl * wg_per_head;
     const int head = hl * 8 + xcd;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     const int S = p.S;
     const int Sk = p.Sk;
     const int coff = CAUSAL ? Sk - S : 0;      // key <= query + coff
-    const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
+    const int n_pass = (paired && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
     const elem_t* qh = reinterpret_cast<const elem_t*>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     u32x4 qf[QB][KS];          // Q fragments of the current pass (the next pass's are loaded behind its epilogue)
 
   for (int pass = 0; pass < n_pass; ++pass) {
-    const int qb = CAUSAL ? (pass == 0 ? p.nqb - 1 - tq : tq) : tq;
+    const int qb = CAUSAL ? ((pass == 0) ? p.nqb - 1 - tq : tq) : tq;      // (unpaired: one pass, longest blocks first)
     // lane coordinates, made opaque per pass: everything derived from them (addresses, mask indices) is then
     // recomputed inside the pass instead of being hoisted out of the pass loop and spilled around it
     int lane = tid & 63;

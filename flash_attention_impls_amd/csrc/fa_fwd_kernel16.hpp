@@ -79,7 +79,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int bid = blockIdx.x;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int wg_per_head = CAUSAL ? (p.nqb + 1) / 2 : p.nqb;
+    // causal: a workgroup takes the query-block pair (nqb-1-t, t) -- equal work for every workgroup -- unless the launch is
+    // so small that every query block can have a CU of its own (p.unpaired: then the longest block alone sets the time)
+    const bool paired = CAUSAL && !p.unpaired;
+    const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
     const int hl = slot / wg_per_head;
     const int tq = slot - hl * wg_per_head;
     const int head = hl * 8 + xcd;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int S = p.S;                         // query rows
     const int Sk = p.Sk;                       // keys
     const int coff = CAUSAL ? Sk - S : 0;      // bottom-right aligned causal mask: key <= query + coff (coff < 0: queries without keys give O = 0, LSE = -inf)
-    const int n_pass = (CAUSAL && (p.nqb - 1 - tq != tq)) ? 2 : 1;
+    const int n_pass = (paired && (p.nqb - 1 - tq != tq)) ? 2 : 1;
 
     using elem_t = unsigned short;
     const char* qh = reinterpret_cast<const char*>(p.q) + (b * p.q_sb + h * p.q_sh) * QKB;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     u32x2 qf8[2][QK8 ? KS : 1];    // ... fp8 Q: eight bytes per lane and k-step
 
   for (int pass = 0; pass < n_pass; ++pass) {
-    const int qb = CAUSAL ? (pass == 0 ? p.nqb - 1 - tq : tq) : tq;
+    const int qb = CAUSAL ? ((pass == 0) ? p.nqb - 1 - tq : tq) : tq;      // (unpaired: one pass, longest blocks first)
     // lane coordinates, opaque per pass (keeps derived values from being hoisted out of the pass loop and spilled)
     int lane = tid & 63;
     asm volatile("" : "+v"(lane));
