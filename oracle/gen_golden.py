@@ -18,6 +18,8 @@ saves), "delta" = rowsum(do*o).  Where the reference's Triton _bwd_kernel can be
 D<=64, N a multiple of 128) its results are stored as "dq_kernel","dk_kernel","dv_kernel": its dV agrees
 with autograd, its dQ/dK do NOT (FA2-triton.py:160-161 forms dS = (dP - rowsum_tile(dP*p)*p)*scale
 instead of p*(dP - rowsum(dP*p))*scale) -- recorded as a reference defect, not reproduced.
+Grouped key/value heads (gqa_*.npz, this build's extension): the reference's sdpa_reference on K, V expanded with
+repeat_interleave; "o" fp32, "dk","dv" the autograd sums over each group.
 "lse" is computed in float64 from the dtype-rounded inputs (log-sum-exp of
 scale*q.k over unmasked keys); where the interpreted reference kernel ran,
 lse == m + log(l) is asserted to 2e-3 (fp16 kernel arithmetic).
@@ -190,9 +192,49 @@ def main_bwd():
         print(f"{name}: dq.sum={float(qf.grad.sum()):.6f} dk.sum={float(kf.grad.sum()):.6f} dv.sum={float(vf.grad.sum()):.6f}")
 
 
+# grouped key/value heads (this build's extension; the reference's operator takes equal head counts): the reference's
+# own sdpa_reference is run on K, V expanded with repeat_interleave -- query head h attends to key/value head h // G --
+# and autograd sums the gradients of a group back onto its key/value head
+GQA_CASES = [
+    # name, B, H, Hkv, S, D, dtype, causal, seed
+    ("gqa_bf16_causal_h4_kv2", 1, 4, 2, 130, 64,  "bf16", True, 21),
+    ("gqa_fp16_nc_h3_kv1",     1, 3, 1, 70,  128, "fp16", False, 22),
+]
+
+
+def main_gqa():
+    ref = load_reference()
+    for (name, B, H, Hkv, S, D, dtype, causal, seed) in GQA_CASES:
+        g = torch.Generator().manual_seed(seed)
+        dt = TORCH_DT[dtype]
+        G = H // Hkv
+        q = torch.randn(B, H, S, D, generator=g).to(dt)
+        k = torch.randn(B, Hkv, S, D, generator=g).to(dt)
+        v = torch.randn(B, Hkv, S, D, generator=g).to(dt)
+        do = torch.randn(B, H, S, D, generator=g).to(dt)
+        qf, kf, vf = [t.float().requires_grad_(True) for t in (q, k, v)]
+        o32 = ref.sdpa_reference(qf, kf.repeat_interleave(G, dim=1), vf.repeat_interleave(G, dim=1), causal=causal)
+        o32.backward(do.float())
+        scale = 1.0 / math.sqrt(D)
+        s = torch.einsum("bhid,bhjd->bhij", q.double(), k.double().repeat_interleave(G, dim=1)) * scale
+        if causal:
+            s = s.masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], float("-inf"))
+        store = {"q": to_storage(q, dtype), "k": to_storage(k, dtype), "v": to_storage(v, dtype), "do": to_storage(do, dtype),
+                 "o": o32.detach().numpy().copy(), "lse": torch.logsumexp(s, dim=-1).numpy().astype(np.float32),
+                 "dq": qf.grad.numpy().copy(), "dk": kf.grad.numpy().copy(), "dv": vf.grad.numpy().copy()}
+        meta = dict(B=B, H=H, Hkv=Hkv, S=S, D=D, causal=int(causal), seed=seed)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), dtype=np.array(dtype),
+                            **{k_: np.array(v_) for k_, v_ in meta.items()}, **store)
+        print(f"{name}: o.sum={float(o32.sum()):.6f} dk.sum={float(kf.grad.sum()):.6f} dv.sum={float(vf.grad.sum()):.6f}")
+
+
 if __name__ == "__main__":
+    if "--gqa-only" in sys.argv:
+        main_gqa()
+        sys.exit(0)
     if not os.path.exists(REF):
         sys.exit("reference not present: golden vectors can only be generated in the build container")
     if "--bwd-only" not in sys.argv:
         main()
     main_bwd()
+    main_gqa()

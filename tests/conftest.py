@@ -28,12 +28,17 @@ def _all_golden():
 
 def golden_names():
     """Forward fixtures."""
-    return [n for n in _all_golden() if not n.startswith("bwd_")]
+    return [n for n in _all_golden() if not n.startswith(("bwd_", "gqa_"))]
 
 
 def golden_bwd_names():
     """Backward fixtures (q,k,v,do,o,lse,delta,dq,dk,dv)."""
     return [n for n in _all_golden() if n.startswith("bwd_")]
+
+
+def golden_gqa_names():
+    """Grouped key/value head fixtures (q (B,H,S,D); k,v (B,Hkv,S,D); do, o, lse, dq, dk, dv)."""
+    return [n for n in _all_golden() if n.startswith("gqa_")]
 
 
 def load_golden(name):

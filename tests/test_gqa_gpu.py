@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOL
+from conftest import TOL, golden_gqa_names, golden_torch, load_golden
 from oracle import attn_oracle as orc
 from test_bwd_gpu import DT, assert_grad_close
 
@@ -91,6 +91,20 @@ def test_gqa_forward_backward(B, H, Hkv, S, D, dt, causal):
     e_gqa = np.linalg.norm(dk.float().cpu().numpy() - dk_ref)
     e_sum = np.linalg.norm(dk_sum - dk_ref)
     assert e_gqa <= 1.5 * e_sum + 1e-6, (e_gqa, e_sum)
+
+
+@pytest.mark.parametrize("name", golden_gqa_names())
+def test_gqa_reference_generated_fixtures(name):
+    """Fixtures made by the reference's own sdpa_reference on expanded K, V (oracle/gen_golden.py --gqa-only)."""
+    d = load_golden(name)
+    q, k, v, do = [golden_torch(d, n, "cuda") for n in ("q", "k", "v", "do")]
+    o, lse, dq, dk, dv = grads(q, k, v, do, bool(d["causal"]))
+    dt = d["dtype"]
+    err = np.abs(o.float().cpu().numpy() - d["o"]).max()
+    assert err <= TOL[dt] * max(1.0, np.abs(d["o"]).max()), err
+    assert np.abs(lse.cpu().numpy() - d["lse"]).max() <= 2e-3
+    for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert_grad_close(got, d[key], dt, f"{name}:{key}")
 
 
 def test_gqa_fp8_forward_matches_expanded():

@@ -128,3 +128,24 @@ def test_oracle_queries_without_keys_give_zero():
     dq_sq, dk_sq, dv_sq, _ = orc.naive_attention_bwd_f64(q[:, :, N - Nk:], k, v, do[:, :, N - Nk:], causal=True)
     assert (dq[:, :, :N - Nk] == 0).all() and np.allclose(dq[:, :, N - Nk:], dq_sq, atol=1e-14)
     assert np.allclose(dk, dk_sq, atol=1e-13) and np.allclose(dv, dv_sq, atol=1e-13)
+
+
+def test_oracle_matches_reference_generated_grouped_head_fixtures():
+    """gqa_*.npz: the reference's own sdpa_reference on K, V expanded with repeat_interleave (oracle/gen_golden.py).
+    Pins what "query head h attends to key/value head h // G" means, forward and backward, for the oracle."""
+    from conftest import golden_f32, golden_gqa_names, load_golden
+    names = golden_gqa_names()
+    assert len(names) == 2
+    for name in names:
+        d = load_golden(name)
+        G = d["H"] // int(d["Hkv"])
+        q, k, v, do = [golden_f32(d, n) for n in ("q", "k", "v", "do")]
+        ke, ve = np.repeat(k, G, axis=1), np.repeat(v, G, axis=1)
+        o, lse = orc.naive_attention_f64(q, ke, ve, causal=bool(d["causal"]))
+        assert np.abs(o - d["o"]).max() < 2e-5, name
+        assert np.abs(lse - d["lse"]).max() < 1e-4, name
+        dq, dk, dv, _ = orc.naive_attention_bwd_f64(q, ke, ve, do, causal=bool(d["causal"]))
+        B, Hkv, S, D = k.shape
+        dk, dv = dk.reshape(B, Hkv, G, S, D).sum(2), dv.reshape(B, Hkv, G, S, D).sum(2)
+        for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+            assert np.abs(got - d[key]).max() <= 2e-4 * max(1.0, np.abs(d[key]).max()), (name, key)
