@@ -228,9 +228,52 @@ def main_gqa():
         print(f"{name}: o.sum={float(o32.sum()):.6f} dk.sum={float(kf.grad.sum()):.6f} dv.sum={float(vf.grad.sum()):.6f}")
 
 
+# a key/value length of its own (this build's extension).  The reference's sdpa_reference reshapes k and v with q's N
+# (FA2-triton.py:315-317), so it cannot run S_q != S_k directly; but under the bottom-right aligned causal mask the
+# S_q x S_k problem is the LAST S_q queries of the square S_k problem, so sdpa_reference runs that square problem (random
+# leading queries, zero upstream gradient on them) and the tail rows are stored.  Non-causal S_q != S_k (plain cross
+# attention) has no reference-generated fixture: parity unpinned by the reference, anchored on the float64 oracle.
+KVLEN_CASES = [
+    # name, B, H, Sq, Sk, D, dtype, causal, seed
+    ("kvlen_bf16_causal_tail_70x200", 1, 2, 70, 200, 64,  "bf16", True, 31),
+    ("kvlen_fp16_causal_tail_33x150", 1, 2, 33, 150, 128, "fp16", True, 32),
+]
+
+
+def main_kvlen():
+    ref = load_reference()
+    for (name, B, H, Sq, Sk, D, dtype, causal, seed) in KVLEN_CASES:
+        g = torch.Generator().manual_seed(seed)
+        dt = TORCH_DT[dtype]
+        Sfull = Sk if causal else Sq
+        qfull = torch.randn(B, H, Sfull, D, generator=g).to(dt)
+        k = torch.randn(B, H, Sk, D, generator=g).to(dt)
+        v = torch.randn(B, H, Sk, D, generator=g).to(dt)
+        dofull = torch.randn(B, H, Sfull, D, generator=g).to(dt)
+        lead = Sfull - Sq
+        dofull[:, :, :lead] = 0
+        qf, kf, vf = [t.float().requires_grad_(True) for t in (qfull, k, v)]
+        o32 = ref.sdpa_reference(qf, kf, vf, causal=causal)
+        o32.backward(dofull.float())
+        scale = 1.0 / math.sqrt(D)
+        s = torch.einsum("bhid,bhjd->bhij", qfull.double(), k.double()) * scale
+        if causal:
+            s = s.masked_fill(torch.arange(Sk)[None, :] > torch.arange(Sfull)[:, None], float("-inf"))
+        lse = torch.logsumexp(s, dim=-1)
+        store = {"q": to_storage(qfull[:, :, lead:].contiguous(), dtype), "k": to_storage(k, dtype), "v": to_storage(v, dtype),
+                 "do": to_storage(dofull[:, :, lead:].contiguous(), dtype),
+                 "o": o32.detach()[:, :, lead:].numpy().copy(), "lse": lse[:, :, lead:].numpy().astype(np.float32),
+                 "dq": qf.grad[:, :, lead:].numpy().copy(), "dk": kf.grad.numpy().copy(), "dv": vf.grad.numpy().copy()}
+        meta = dict(B=B, H=H, S=Sq, Sk=Sk, D=D, causal=int(causal), seed=seed)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), dtype=np.array(dtype),
+                            **{k_: np.array(v_) for k_, v_ in meta.items()}, **store)
+        print(f"{name}: o.sum={float(o32[:, :, lead:].sum()):.6f} dk.sum={float(kf.grad.sum()):.6f} dv.sum={float(vf.grad.sum()):.6f}")
+
+
 if __name__ == "__main__":
-    if "--gqa-only" in sys.argv:
+    if "--gqa-only" in sys.argv or "--ext-only" in sys.argv:
         main_gqa()
+        main_kvlen()
         sys.exit(0)
     if not os.path.exists(REF):
         sys.exit("reference not present: golden vectors can only be generated in the build container")
@@ -238,3 +281,4 @@ if __name__ == "__main__":
         main()
     main_bwd()
     main_gqa()
+    main_kvlen()

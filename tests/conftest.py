@@ -28,7 +28,7 @@ def _all_golden():
 
 def golden_names():
     """Forward fixtures."""
-    return [n for n in _all_golden() if not n.startswith(("bwd_", "gqa_"))]
+    return [n for n in _all_golden() if not n.startswith(("bwd_", "gqa_", "kvlen_"))]
 
 
 def golden_bwd_names():
@@ -39,6 +39,11 @@ def golden_bwd_names():
 def golden_gqa_names():
     """Grouped key/value head fixtures (q (B,H,S,D); k,v (B,Hkv,S,D); do, o, lse, dq, dk, dv)."""
     return [n for n in _all_golden() if n.startswith("gqa_")]
+
+
+def golden_kvlen_names():
+    """Fixtures with a key/value length of its own (q (B,H,S,D); k,v (B,H,Sk,D); do, o, lse, dq, dk, dv)."""
+    return [n for n in _all_golden() if n.startswith("kvlen_")]
 
 
 def load_golden(name):

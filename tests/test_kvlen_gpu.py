@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOL
+from conftest import TOL, golden_kvlen_names, golden_torch, load_golden
 from oracle import attn_oracle as orc
 from test_bwd_gpu import DT, assert_grad_close
 
@@ -86,6 +86,21 @@ def test_other_key_length_forward_backward(B, H, Hkv, Sq, Sk, D, dt, causal):
     assert_grad_close(dq, dq_ref, dt, tag + ":dq")
     assert_grad_close(dk, dk_ref, dt, tag + ":dk")
     assert_grad_close(dv, dv_ref, dt, tag + ":dv")
+
+
+@pytest.mark.parametrize("name", golden_kvlen_names())
+def test_reference_generated_key_length_fixtures(name):
+    """Fixtures from the reference's sdpa_reference on the square S_k problem (its last S_q rows): the one way the
+    reference itself can speak about S_q != S_k (oracle/gen_golden.py --ext-only)."""
+    d = load_golden(name)
+    q, k, v, do = [golden_torch(d, n, "cuda") for n in ("q", "k", "v", "do")]
+    o, lse, dq, dk, dv = grads(q, k, v, do, True)
+    dt = d["dtype"]
+    err = np.abs(o.float().cpu().numpy() - d["o"]).max()
+    assert err <= TOL[dt] * max(1.0, np.abs(d["o"]).max()), err
+    assert np.abs(lse.cpu().numpy() - d["lse"]).max() <= 2e-3
+    for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert_grad_close(got, d[key], dt, f"{name}:{key}")
 
 
 @pytest.mark.parametrize("Sq,Sk,D", [(128, 512, 128), (90, 347, 128), (256, 1024, 64)])

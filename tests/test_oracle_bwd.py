@@ -149,3 +149,20 @@ def test_oracle_matches_reference_generated_grouped_head_fixtures():
         dk, dv = dk.reshape(B, Hkv, G, S, D).sum(2), dv.reshape(B, Hkv, G, S, D).sum(2)
         for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
             assert np.abs(got - d[key]).max() <= 2e-4 * max(1.0, np.abs(d[key]).max()), (name, key)
+
+
+def test_oracle_matches_reference_generated_key_length_fixtures():
+    """kvlen_*.npz: the reference's sdpa_reference on the square S_k problem, last S_q query rows stored
+    (oracle/gen_golden.py): pins the bottom-right aligned causal mask of the oracle, forward and backward."""
+    from conftest import golden_f32, golden_kvlen_names, load_golden
+    names = golden_kvlen_names()
+    assert len(names) == 2
+    for name in names:
+        d = load_golden(name)
+        q, k, v, do = [golden_f32(d, n) for n in ("q", "k", "v", "do")]
+        assert q.shape[2] == d["S"] and k.shape[2] == int(d["Sk"]) != d["S"]
+        o, lse = orc.naive_attention_f64(q, k, v, causal=True)
+        assert np.abs(o - d["o"]).max() < 2e-5 and np.abs(lse - d["lse"]).max() < 1e-4, name
+        dq, dk, dv, _ = orc.naive_attention_bwd_f64(q, k, v, do, causal=True)
+        for got, key in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+            assert np.abs(got - d[key]).max() <= 2e-4 * max(1.0, np.abs(d[key]).max()), (name, key)
