@@ -84,6 +84,47 @@ int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int
     return FA_OK;
 }
 
+// Parts a key/value head's group of G query heads is split into for the dK/dV kernel.  One workgroup per (key block,
+// key/value head) streams all G query heads; with few key/value heads and a small batch (multi-query attention above
+// all) that is too few, too unequal workgroups for 256 CUs.  Splitting the group over `parts` workgroups multiplies the
+// grid; each part writes fp32 partial sums and fa_bwd_reduce_kernel adds them up (fixed order: still deterministic).
+// Measured (cfg3-like shapes with 1 ... 8 key/value heads, S = 4096 ... 16384): under the causal mask, where workgroups
+// are of very unequal length, splitting pays up to about 2048 workgroups; without it only until the chip is full.
+int dkdv_parts(int B, int H_kv, int G, int S_k, bool causal)
+{
+    if (G <= 1) return 1;
+    const long long want = causal ? 2048 : 512;
+    const long long wgs = (long long)B * H_kv * ((S_k + 127) / 128);
+    if (wgs >= want) return 1;                       // enough workgroups for the dispatcher to balance
+    int parts = 1;
+    for (int d = 2; d <= G; ++d)
+        if (G % d == 0) { parts = d; if (wgs * d >= want) break; }
+    return parts;
+}
+
+size_t stats_bytes(int B, int H, int S)
+{
+    const size_t spad = ((size_t)S + fa::kBN - 1) / fa::kBN * fa::kBN;
+    return (size_t)2 * B * H * spad * sizeof(float);
+}
+
+size_t partial_bytes(int B, int H_kv, int parts, int S_k, int D)       // one of the two fp32 partial tensors
+{
+    return parts > 1 ? (size_t)B * H_kv * parts * S_k * D * sizeof(float) : 0;
+}
+
+template <class T>
+int run_reduce(const float* part, void* out, int B, int Hkv, int S, int dv, int parts, long long sb, long long sh, long long ss, hipStream_t s)
+{
+    const long long total8 = (long long)B * Hkv * S * (dv / 8);
+    const long long blocks = (total8 + 255) / 256;
+    if (blocks > 0x7FFFFFFFll) return fail(FA_ERR_TOO_LARGE, "reduction grid too large");
+    hipLaunchKernelGGL((fa::fa_bwd_reduce_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, part, out, Hkv, S, dv, parts, total8, sb, sh, ss);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "dK/dV reduction launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 int bwd_grid(long long bh, long long blocks_per_head)
 {
     const long long g = ((bh + 7) / 8) * 8 * blocks_per_head;   // heads padded to a multiple of 8 XCD groups
@@ -97,8 +138,14 @@ extern "C" {
 size_t fa_bwd_workspace_bytes(int B, int H, int S)
 {
     if (B <= 0 || H <= 0 || S <= 0) return 0;
-    const size_t spad = ((size_t)S + fa::kBN - 1) / fa::kBN * fa::kBN;
-    return (size_t)2 * B * H * spad * sizeof(float);
+    return stats_bytes(B, H, S);
+}
+
+size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D)
+{
+    if (B <= 0 || H <= 0 || H_kv <= 0 || S_q <= 0 || S_k <= 0 || D <= 0 || H % H_kv != 0) return 0;
+    const int parts = dkdv_parts(B, H_kv, H / H_kv, S_k, /*causal=*/true);      // (the causal mask splits further)
+    return ((stats_bytes(B, H, S_q) + 255) / 256) * 256 + 2 * partial_bytes(B, H_kv, parts, S_k, D);
 }
 
 int fa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
@@ -196,9 +243,23 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     pq.o1_sb = st[5][0]; pq.o1_sh = st[5][1]; pq.o1_ss = st[5][2];
     pq.nxb = (S + 32 * fa::bwd_waves<0>() - 1) / (32 * fa::bwd_waves<0>());
     // dK, dV: stationary K, V (the grid runs over the key/value heads); streamed Q, dO of the group's query heads
-    pk.H = H_kv; pk.bh = B * H_kv;
+    // a group split over several workgroups if that helps and the caller's workspace (fa_bwd_ex_workspace_bytes) has room
+    // for the fp32 partial sums; with the smaller fa_bwd_workspace_bytes the unsplit kernel runs
+    int parts = dkdv_parts(B, H_kv, H / H_kv, S_k, causal != 0);
+    const size_t part_off = ((stats_bytes(B, H, S) + 255) / 256) * 256;
+    const size_t part_one = partial_bytes(B, H_kv, parts, S_k, D);
+#if defined(FA_BWD_DKDV_SINGLE)
+    parts = 1;
+#endif
+    if (parts > 1 && workspace_bytes < part_off + 2 * part_one) parts = 1;
+    pk.xsplit = parts;
+    pk.G = (H / H_kv) / parts;
+    pk.H = H_kv * parts; pk.bh = B * H_kv * parts;
     pk.S = S_k; pk.Sy = S;
     pk.x1 = k; pk.x2 = v; pk.y1 = q; pk.y2 = d_o; pk.out1 = dk; pk.out2 = dv;
+    float* part_dk = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_off);
+    float* part_dv = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_off + part_one);
+    if (parts > 1) { pk.out1 = part_dk; pk.out2 = part_dv; }
     pk.x1_sb = st[1][0]; pk.x1_sh = st[1][1]; pk.x1_ss = st[1][2];
     pk.x2_sb = st[2][0]; pk.x2_sh = st[2][1]; pk.x2_ss = st[2][2];
     pk.y1_sb = st[0][0]; pk.y1_sh = st[0][1]; pk.y1_ss = st[0][2];
@@ -211,12 +272,23 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     // have one of the 256 CUs to itself
     pq.unpaired = (causal != 0 && pq.nxb > 1 && (((long long)B * H + 7) / 8) * 8 * pq.nxb <= 256) ? 1 : 0;
     const int grid_q = bwd_grid((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);
-    const int grid_k = bwd_grid((long long)B * H_kv, pk.nxb);
+    const int grid_k = bwd_grid((long long)B * H_kv * parts, pk.nxb);
     if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     const bool c = causal != 0;
     if (dtype == FA_DTYPE_BF16)
-        return big ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
-    return big ? run_bwd<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
+        rc = big ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
+    else
+        rc = big ? run_bwd<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
+    if (rc != FA_OK || parts == 1) return rc;
+    // the parts' fp32 partial sums -> dK, dV (16-bit, caller's strides)
+    for (int which = 0; which < 2 && rc == FA_OK; ++which) {
+        const float* src = which == 0 ? part_dk : part_dv;
+        void* dst = which == 0 ? dk : dv;
+        const long long* so = st[6 + which];
+        rc = dtype == FA_DTYPE_BF16 ? run_reduce<fa::TypeBF16>(src, dst, B, H_kv, S_k, D, parts, so[0], so[1], so[2], s)
+                                    : run_reduce<fa::TypeF16>(src, dst, B, H_kv, S_k, D, parts, so[0], so[1], so[2], s);
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -73,8 +73,10 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const int x0w = x0 + pair * 32;            // first key of this wave pair
 
     using elem_t = unsigned short;
-    const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + h * p.x1_sh;     // K
-    const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + h * p.x2_sh;     // V
+    // (grid head h = key/value head * xsplit + part: the parts of a group share K and V and split its query heads)
+    const int hx = h / p.xsplit;
+    const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + hx * p.x1_sh;    // K
+    const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + hx * p.x2_sh;    // V
     // Q and dO of the G query heads that share this key/value head (h G .. h G + G-1) are streamed one head after the other
     const int headq0 = head * p.G;                                                             // first of them, counted over all batches
     const int bhq = p.bh * p.G;                                                                // query heads in all
@@ -363,7 +365,26 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     else block_grads(IC<ST>{}, IC<0>{});
                 }
             });
-        // epilogue: dK * scale, dV; layout and stores as fa_bwd_kernel.hpp
+        // epilogue: dK * scale, dV; layout and stores as fa_bwd_kernel.hpp -- or, when a group is split over several
+        // workgroups, this part's fp32 partial sums (contiguous [B][grid heads][S][dv], 16 bytes per lane and tile)
+        if (p.xsplit > 1) {
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                float* ph = reinterpret_cast<float*>(which == 0 ? p.out1 : p.out2) + ((long long)head * S) * p.dv;
+                const float mult = which == 0 ? p.scale : 1.0f;
+#pragma unroll
+                for (int xt = 0; xt < 2; ++xt) {
+                    const int xrow = x0w + 16 * xt + li;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const f32x4 a = (which == 0 ? acc1[dt][xt] : acc2[dt][xt]) * mult;
+                        const int col = 16 * dt + 4 * lg;
+                        if (xrow < S && col < p.dv) *reinterpret_cast<f32x4*>(ph + (long long)xrow * p.dv + col) = a;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             elem_t* oh = which == 0 ? reinterpret_cast<elem_t*>(p.out1) + b * p.o1_sb + h * p.o1_sh

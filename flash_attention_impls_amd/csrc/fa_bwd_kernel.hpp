@@ -54,6 +54,9 @@ struct BwdParams {
     int bh;                             // B*H
     int nxb;                            // stationary blocks per head
     int unpaired;                       // MODE 0, causal: 1 = one query block per workgroup (small grids), 0 = block pairs
+    int xsplit;                         // dK/dV kernel: a key/value head's group of query heads is split over `xsplit` workgroups
+                                        // (grid heads = key/value heads x xsplit, G = query heads per part); > 1: out1 / out2 are
+                                        // fp32 partial sums [B][H][S][D] that fa_bwd_reduce_kernel adds up
     long long x1_sb, x1_sh, x1_ss;      // element strides (head_dim stride is 1)
     long long x2_sb, x2_sh, x2_ss;
     long long y1_sb, y1_sh, y1_ss;
@@ -124,6 +127,34 @@ __global__ __launch_bounds__(256) void fa_bwd_prep_kernel(const void* __restrict
         stats[idx] = l2;
         stats[(long long)bh * Spad + idx] = -acc;        // stored negated: it seeds the dP accumulators
     }
+}
+
+// Sum of the `parts` fp32 partial dK (or dV) tensors of a key/value head, written once in the 16-bit output type:
+// part[b][hk * parts + j][s][0..D) over j.  HBM-bound; one thread per 8 output elements (two 16-byte loads per part).
+template <class T>
+__global__ __launch_bounds__(256) void fa_bwd_reduce_kernel(const float* __restrict__ part, void* __restrict__ out,
+                                                            int Hkv, int S, int dv, int parts, long long total8,
+                                                            long long o_sb, long long o_sh, long long o_ss)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total8) return;
+    const int c8 = dv / 8;
+    const int col = (int)(t % c8) * 8;
+    const long long row = t / c8;                    // (b * Hkv + hk) * S + s
+    const int srow = (int)(row % S);
+    const long long bh = row / S;
+    const int hk = (int)(bh % Hkv);
+    const long long b = bh / Hkv;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < parts; ++j) {
+        const float* src = part + (((bh * parts + j) * S + srow) * (long long)dv + col);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), c = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += c[e]; }
+    }
+    const u32x4 w = {T::pack2(acc[0], acc[1]), T::pack2(acc[2], acc[3]), T::pack2(acc[4], acc[5]), T::pack2(acc[6], acc[7])};
+    unsigned short* dst = reinterpret_cast<unsigned short*>(out) + b * o_sb + hk * o_sh + (long long)srow * o_ss + col;
+    *reinterpret_cast<u32x4*>(dst) = w;
 }
 
 // (head_dim 64, MODE 0, non-causal: 128 VGPRs and 48 KiB of LDS let two workgroups share a CU: +3 %; the causal variant

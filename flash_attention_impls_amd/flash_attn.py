@@ -101,6 +101,8 @@ def _declare(lib):
     lib.fa_fwd_ex.argtypes = lib.fa_fwd.argtypes[:5] + [c.c_int] * 6 + lib.fa_fwd.argtypes[9:]
     lib.fa_fwd_fp8_ex.restype = c.c_int
     lib.fa_fwd_fp8_ex.argtypes = lib.fa_fwd_fp8.argtypes[:5] + [c.c_int] * 6 + lib.fa_fwd_fp8.argtypes[9:]
+    lib.fa_bwd_ex_workspace_bytes.restype = c.c_size_t
+    lib.fa_bwd_ex_workspace_bytes.argtypes = [c.c_int] * 6
     lib.fa_bwd_ex.restype = c.c_int
     lib.fa_bwd_ex.argtypes = lib.fa_bwd.argtypes[:9] + [c.c_int] * 6 + lib.fa_bwd.argtypes[13:]
     lib.fa_fwd_dispatch.restype = c.c_int
@@ -240,7 +242,7 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     do = _kernel_ready(do.to(q.dtype))
     with torch.cuda.device(q.device), _trace_range("FA2_BWD"):
         stream = torch.cuda.current_stream().cuda_stream
-        nbytes = lib.fa_bwd_workspace_bytes(B, H, N)
+        nbytes = lib.fa_bwd_ex_workspace_bytes(B, H, Hkv, N, Nk, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
         rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
                            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Hkv, N, Nk, D,

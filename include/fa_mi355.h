@@ -151,7 +151,12 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
  * one workgroup per (key block, key/value head): still no atomics, no zero-fill, bitwise deterministic.
  * H_kv == H and S_k == S_q is exactly fa_fwd / fa_fwd_fp8 / fa_bwd.
  * Workspaces: fa_fp8_workspace_bytes(B, H, max(S_q, S_k), D) and fa_bwd_workspace_bytes(B, H, S_q) are sufficient.
+ * fa_bwd_ex_workspace_bytes is the recommended size for fa_bwd_ex: with few key/value heads and a small batch (multi-query
+ * attention above all) it adds room for fp32 partial sums, so that the query heads of a group can be split over several
+ * dK/dV workgroups and summed by a reduction pass (same results up to fp32 summation order, still deterministic); with
+ * the smaller fa_bwd_workspace_bytes the unsplit kernel runs.
  */
+size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D);
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
               int B, int H, int H_kv, int S_q, int S_k, int D,
               const int64_t* q_strides, const int64_t* k_strides,

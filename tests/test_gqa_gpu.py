@@ -156,3 +156,41 @@ def test_gqa_bad_head_counts():
         fa.flash_attn(q, k, k)
     with pytest.raises(fa.FlashAttnArgumentError):
         fa.flash_attn(q, k[:, :3], k[:, :2])
+
+
+def test_gqa_backward_split_and_unsplit_paths_agree():
+    """With few key/value heads and a small batch the dK/dV kernel splits a group's query heads over several workgroups
+    (fp32 partial sums + a reduction pass) when the workspace has room (fa_bwd_ex_workspace_bytes); with the smaller
+    fa_bwd_workspace_bytes one workgroup streams the whole group.  Both paths against the float64 oracle and each other."""
+    import ctypes
+    import importlib
+    host = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    lib = fa.load_library()
+    B, H, Hkv, S, D = 2, 8, 2, 300, 128
+    q, k, v, do = rand_gqa(B, H, Hkv, S, D, torch.bfloat16, seed=5)
+    scale = D ** -0.5
+    o, lse = host._fwd_raw(lib, q, k, v, True, scale, None, True)
+    small, big = lib.fa_bwd_workspace_bytes(B, H, S), lib.fa_bwd_ex_workspace_bytes(B, H, Hkv, S, S, D)
+    assert big > small                                    # this shape is one the library wants to split
+    outs = {}
+    for name, nbytes in (("unsplit", small), ("split", big)):
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Hkv, S, S, D, *([None] * 8),
+                           0, 1, scale, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.fa_last_error()
+        torch.cuda.synchronize()
+        outs[name] = (dq, dk, dv)
+    assert torch.equal(outs["split"][0], outs["unsplit"][0])            # dQ does not depend on the split
+    G = H // Hkv
+    qn, kn, vn, don = [t.float().cpu().numpy() for t in (q, expand(k, G), expand(v, G), do)]
+    _, dk_ref, dv_ref, _ = orc.naive_attention_bwd_f64(qn, kn, vn, don, causal=True)
+    dk_ref = dk_ref.reshape(B, Hkv, G, S, D).sum(axis=2)
+    dv_ref = dv_ref.reshape(B, Hkv, G, S, D).sum(axis=2)
+    for name in ("unsplit", "split"):
+        assert_grad_close(outs[name][1], dk_ref, "bf16", name + ":dk")
+        assert_grad_close(outs[name][2], dv_ref, "bf16", name + ":dv")
+    # the two differ only by fp32 summation order before the final rounding
+    for a, b_ in zip(outs["split"][1:], outs["unsplit"][1:]):
+        assert (a.float() - b_.float()).abs().max() <= 2 ** -7 * max(1.0, b_.float().abs().max().item())

@@ -251,6 +251,12 @@ def test_grouped_query_entry_points_validate_without_gpu():
     assert b"S_k" in lib.fa_last_error()
     assert lib.fa_fwd_fp8_ex(p, p, p, p, null, 1, 2, 2, 8, 0, 128, null, null, null, null, 1, 0.0, null, p, 1 << 20, null) == -3
     assert lib.fa_bwd_ex(*([p] * 9), 1, 2, 2, 8, 0, 128, *([null] * 8), 0, 1, 0.0, p, n, null) == -3
+    # workspace sizes: the extended size adds room for split-group partial sums only where a split is wanted
+    assert lib.fa_bwd_ex_workspace_bytes(8, 32, 32, 4096, 4096, 128) == lib.fa_bwd_workspace_bytes(8, 32, 4096)
+    assert lib.fa_bwd_ex_workspace_bytes(8, 32, 8, 4096, 4096, 128) == lib.fa_bwd_workspace_bytes(8, 32, 4096)   # 2048 workgroups: no split
+    mqa = lib.fa_bwd_ex_workspace_bytes(8, 32, 1, 4096, 4096, 128)
+    assert mqa == lib.fa_bwd_workspace_bytes(8, 32, 4096) + 2 * 8 * 1 * 8 * 4096 * 128 * 4                  # 8 parts, fp32 dK and dV
+    assert lib.fa_bwd_ex_workspace_bytes(1, 6, 4, 8, 8, 128) == 0                                               # H % H_kv != 0
     # host side: k, v may have a head count that divides q's; the "no CPU path" rule comes after the shape rules
     q, k = torch.zeros(1, 6, 8, 64), torch.zeros(1, 2, 8, 64)
     with pytest.raises(fa.FlashAttnArgumentError, match="no CPU path"):
