@@ -90,16 +90,23 @@ int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int
 // grid; each part writes fp32 partial sums and fa_bwd_reduce_kernel adds them up (fixed order: still deterministic).
 // Measured (cfg3-like shapes with 1 ... 8 key/value heads, S = 4096 ... 16384): under the causal mask, where workgroups
 // are of very unequal length, splitting pays up to about 2048 workgroups; without it only until the chip is full.
-int dkdv_parts(int B, int H_kv, int G, int S_k, bool causal)
+// Where the heads of a group do not suffice (or there is no group: G = 1), the visible query range of a key block is
+// split as well (`qparts` workgroups per key block, at least four 64-row tiles each).
+void dkdv_parts(int B, int H_kv, int G, int S_q, int S_k, bool causal, int& gparts, int& qparts)
 {
-    if (G <= 1) return 1;
+    gparts = qparts = 1;
     const long long want = causal ? 2048 : 512;
     const long long wgs = (long long)B * H_kv * ((S_k + 127) / 128);
-    if (wgs >= want) return 1;                       // enough workgroups for the dispatcher to balance
-    int parts = 1;
+    const long long tiles = (S_q + fa::kBN - 1) / fa::kBN;
+    if (wgs >= want) return;                         // enough workgroups for the dispatcher to balance
+    if (tiles * G < 64) return;                      // a workgroup of < 64 tiles (~0.1 ms): the reduction pass would cost more
     for (int d = 2; d <= G; ++d)
-        if (G % d == 0) { parts = d; if (wgs * d >= want) break; }
-    return parts;
+        if (G % d == 0) { gparts = d; if (wgs * d >= want) break; }
+    // the query range is split only where there are fewer workgroups than CUs: its partial sums are as large as dK and
+    // dV themselves per part (measured: with 512 or more workgroups the extra traffic costs more than the balance gains)
+    if (wgs * gparts >= 256) return;
+    const long long more = (512 + wgs * gparts - 1) / (wgs * gparts);
+    qparts = (int)std::max(1ll, std::min(std::min(more, tiles / 4), 8ll));
 }
 
 size_t stats_bytes(int B, int H, int S)
@@ -127,7 +134,7 @@ int run_reduce(const float* part, void* out, int B, int Hkv, int S, int dv, int 
 
 int bwd_grid(long long bh, long long blocks_per_head)
 {
-    const long long g = ((bh + 7) / 8) * 8 * blocks_per_head;   // heads padded to a multiple of 8 XCD groups
+    const long long g = fa_capi::grid_blocks(bh, blocks_per_head, fa_capi::head_split(bh, blocks_per_head));   // (virtual) heads padded to 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
 }
 
@@ -144,8 +151,9 @@ size_t fa_bwd_workspace_bytes(int B, int H, int S)
 size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D)
 {
     if (B <= 0 || H <= 0 || H_kv <= 0 || S_q <= 0 || S_k <= 0 || D <= 0 || H % H_kv != 0) return 0;
-    const int parts = dkdv_parts(B, H_kv, H / H_kv, S_k, /*causal=*/true);      // (the causal mask splits further)
-    return ((stats_bytes(B, H, S_q) + 255) / 256) * 256 + 2 * partial_bytes(B, H_kv, parts, S_k, D);
+    int gp, qp;
+    dkdv_parts(B, H_kv, H / H_kv, S_q, S_k, /*causal=*/true, gp, qp);          // (the causal mask splits further)
+    return ((stats_bytes(B, H, S_q) + 255) / 256) * 256 + 2 * partial_bytes(B, H_kv, gp * qp, S_k, D);
 }
 
 int fa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
@@ -245,15 +253,18 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     // dK, dV: stationary K, V (the grid runs over the key/value heads); streamed Q, dO of the group's query heads
     // a group split over several workgroups if that helps and the caller's workspace (fa_bwd_ex_workspace_bytes) has room
     // for the fp32 partial sums; with the smaller fa_bwd_workspace_bytes the unsplit kernel runs
-    int parts = dkdv_parts(B, H_kv, H / H_kv, S_k, causal != 0);
+    int gparts, qparts;
+    dkdv_parts(B, H_kv, H / H_kv, S, S_k, causal != 0, gparts, qparts);
     const size_t part_off = ((stats_bytes(B, H, S) + 255) / 256) * 256;
-    const size_t part_one = partial_bytes(B, H_kv, parts, S_k, D);
+    size_t part_one = partial_bytes(B, H_kv, gparts * qparts, S_k, D);
 #if defined(FA_BWD_DKDV_SINGLE)
-    parts = 1;
+    gparts = qparts = 1;
 #endif
-    if (parts > 1 && workspace_bytes < part_off + 2 * part_one) parts = 1;
-    pk.xsplit = parts;
-    pk.G = (H / H_kv) / parts;
+    if (gparts * qparts > 1 && workspace_bytes < part_off + 2 * part_one) gparts = qparts = 1;
+    const int parts = gparts * qparts;
+    pk.xsplit = gparts;
+    pk.qsplit = qparts;
+    pk.G = (H / H_kv) / gparts;
     pk.H = H_kv * parts; pk.bh = B * H_kv * parts;
     pk.S = S_k; pk.Sy = S;
     pk.x1 = k; pk.x2 = v; pk.y1 = q; pk.y2 = d_o; pk.out1 = dk; pk.out2 = dv;
@@ -271,6 +282,8 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp), unless every block can
     // have one of the 256 CUs to itself
     pq.unpaired = (causal != 0 && pq.nxb > 1 && (((long long)B * H + 7) / 8) * 8 * pq.nxb <= 256) ? 1 : 0;
+    pq.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);
+    pk.hsplit = fa_capi::head_split((long long)pk.bh, pk.nxb);
     const int grid_q = bwd_grid((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);
     const int grid_k = bwd_grid((long long)B * H_kv * parts, pk.nxb);
     if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");

@@ -57,15 +57,12 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const int li = lane & 15;
     const int lg = lane >> 4;
 
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int slot = bid >> 3;
-    const int hl = slot / p.nxb;
-    const int xb = slot - hl * p.nxb;          // key blocks in launch order: heaviest (first) first under the causal mask
-    const int head = hl * 8 + xcd;
-    if (head >= p.bh) return;
+    int head, xb;                              // key blocks in launch order: heaviest (first) first under the causal mask
+    if (!wg_decode(blockIdx.x, p.bh, p.nxb, p.hsplit, head, xb)) return;
     const int b = head / p.H;
-    const int h = head - b * p.H;
+    const int hq = head - b * p.H;             // grid head = (key/value head * xsplit + group part) * qsplit + query-range part
+    const int h = hq / p.qsplit;
+    const int qpart = hq - h * p.qsplit;
     const int S = p.S;                         // keys
     const int Sy = p.Sy;                       // queries
     const int coff = CAUSAL ? p.coff : 0;      // key <= query + coff
@@ -78,15 +75,15 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const elem_t* x1h = reinterpret_cast<const elem_t*>(p.x1) + b * p.x1_sb + hx * p.x1_sh;    // K
     const elem_t* x2h = reinterpret_cast<const elem_t*>(p.x2) + b * p.x2_sb + hx * p.x2_sh;    // V
     // Q and dO of the G query heads that share this key/value head (h G .. h G + G-1) are streamed one head after the other
-    const int headq0 = head * p.G;                                                             // first of them, counted over all batches
-    const int bhq = p.bh * p.G;                                                                // query heads in all
+    const int headq0 = (b * (p.H / p.qsplit) + h) * p.G;                                       // first of them, counted over all batches
+    const int bhq = (p.bh / p.qsplit) * p.G;                                                   // query heads in all
     const elem_t* y1h = reinterpret_cast<const elem_t*>(p.y1) + b * p.y1_sb + (h * p.G) * p.y1_sh;   // Q
     const elem_t* y2h = reinterpret_cast<const elem_t*>(p.y2) + b * p.y2_sb + (h * p.G) * p.y2_sh;   // dO
 
     // ---- streamed range of the workgroup (tiles) and of this pair (blocks)
     const int nty = (Sy + kBN - 1) / kBN;
     int j_begin = 0;
-    const int j_end = nty;
+    int j_end = nty;
     int blk_begin_w = 0, blk_end_w = (Sy + 31) / 32;
     int blk_mask = 0, blk_mask_hi = -1;                   // the diagonal block(s): two when coff is not a multiple of 32
     if constexpr (CAUSAL) {
@@ -95,6 +92,13 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
         blk_begin_w = max(0, q_lo) >> 5;                  // earlier blocks hold only queries that see none of this pair's keys
         blk_mask = blk_begin_w;
         blk_mask_hi = (q_lo + 31 < 0) ? -1 : (q_lo + 31) >> 5;
+    }
+    if (p.qsplit > 1) {                                   // this workgroup's share of the visible query tiles
+        const int per = (j_end - j_begin + p.qsplit - 1) / p.qsplit;
+        j_begin = min(j_end, j_begin + qpart * per);
+        j_end = min(j_end, j_begin + per);
+        blk_begin_w = max(blk_begin_w, 2 * j_begin);
+        blk_end_w = min(blk_end_w, 2 * j_end);
     }
     if (x0w >= S) { blk_begin_w = 0; blk_end_w = 0; }     // no keys: staging duty only
 
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             });
         // epilogue: dK * scale, dV; layout and stores as fa_bwd_kernel.hpp -- or, when a group is split over several
         // workgroups, this part's fp32 partial sums (contiguous [B][grid heads][S][dv], 16 bytes per lane and tile)
-        if (p.xsplit > 1) {
+        if (p.xsplit * p.qsplit > 1) {
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
                 float* ph = reinterpret_cast<float*>(which == 0 ? p.out1 : p.out2) + ((long long)head * S) * p.dv;

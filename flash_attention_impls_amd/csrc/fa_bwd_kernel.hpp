@@ -54,9 +54,12 @@ struct BwdParams {
     int bh;                             // B*H
     int nxb;                            // stationary blocks per head
     int unpaired;                       // MODE 0, causal: 1 = one query block per workgroup (small grids), 0 = block pairs
+    int hsplit;                         // virtual heads per head of the grid mapping (wg_decode in fa_fwd_kernel.hpp)
     int xsplit;                         // dK/dV kernel: a key/value head's group of query heads is split over `xsplit` workgroups
                                         // (grid heads = key/value heads x xsplit, G = query heads per part); > 1: out1 / out2 are
                                         // fp32 partial sums [B][H][S][D] that fa_bwd_reduce_kernel adds up
+    int qsplit;                         // dK/dV kernel: the visible query range of a key block is split over `qsplit` workgroups
+                                        // (grid heads = key/value heads x xsplit x qsplit; partial sums whenever xsplit * qsplit > 1)
     long long x1_sb, x1_sh, x1_ss;      // element strides (head_dim stride is 1)
     long long x2_sb, x2_sh, x2_ss;
     long long y1_sb, y1_sh, y1_ss;
@@ -185,19 +188,14 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     int lane = tid & 63;
 
     // workgroup -> (head, stationary block); blockIdx % 8 = XCD: all blocks of a head share one L2
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int slot = bid >> 3;
     // MODE 0 under the causal mask: a workgroup takes the query-block pair (nxb-1-t, t), so that every workgroup
     // streams nxb+1 blocks' worth of tiles (a balanced grid, as in the forward); MODE 1 launches the heaviest key
     // blocks (the first ones) first
     constexpr bool PAIRABLE = MODE == 0 && CAUSAL;
     const bool PAIR = PAIRABLE && !p.unpaired;
     const int wg_per_head = PAIR ? (p.nxb + 1) / 2 : p.nxb;
-    const int hl = slot / wg_per_head;
-    const int t = slot - hl * wg_per_head;
-    const int head = hl * 8 + xcd;
-    if (head >= p.bh) return;
+    int head, t;
+    if (!wg_decode(blockIdx.x, p.bh, wg_per_head, p.hsplit, head, t)) return;
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;

@@ -141,7 +141,7 @@ int grid_for(int B, int H, int S, bool causal)
     const long long bh = (long long)B * H;
     const long long nqb = (S + fa::kBM - 1) / fa::kBM;
     const long long per_head = (causal && !unpaired_for(B, H, S, causal)) ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
-    const long long g = ((bh + 7) / 8) * 8 * per_head;         // heads padded to a multiple of 8 XCD groups
+    const long long g = fa_capi::grid_blocks(bh, per_head, fa_capi::head_split(bh, per_head));   // (virtual) heads padded to a multiple of 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
 }
 
@@ -212,6 +212,10 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.dv = D;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.unpaired = unpaired_for(B, H, S, causal != 0) ? 1 : 0;
+    {
+        const long long nqb_ = (S + fa::kBM - 1) / fa::kBM;
+        p.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !p.unpaired) ? (nqb_ + 1) / 2 : nqb_);
+    }
     p.bh = B * H;
     if (!set_strides(q_strides, H, S, D, p.q_sb, p.q_sh, p.q_ss) ||
         !set_strides(k_strides, H_kv, S_k, D, p.k_sb, p.k_sh, p.k_ss) ||
@@ -336,6 +340,10 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     p.G = H / H_kv;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
     p.unpaired = unpaired_for(B, H, S, causal != 0) ? 1 : 0;
+    {
+        const long long nqb_ = (S + fa::kBM - 1) / fa::kBM;
+        p.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !p.unpaired) ? (nqb_ + 1) / 2 : nqb_);
+    }
     p.bh = B * H;
     p.q_sb = st[0][0]; p.q_sh = st[0][1]; p.q_ss = st[0][2];
     p.k_sb = st[1][0]; p.k_sh = st[1][1]; p.k_ss = st[1][2];

@@ -27,6 +27,25 @@ inline bool set_strides(const int64_t* s, int H, int S, int D, long long& sb, lo
     return sb >= 0 && sh >= 0 && ss >= D;
 }
 
+// Grid mapping shared by all kernels (wg_decode in fa_fwd_kernel.hpp): blockIdx % 8 = XCD, all blocks of a (batch, head)
+// slice on one XCD.  A head count that is small and not a multiple of 8 would leave XCDs idle (4 heads: half the chip):
+// each head then becomes 2, 4 or 8 virtual heads that share its blocks, so that the virtual heads fill all 8 XCDs evenly.
+// (From 64 heads on the idle share is below 10 % and keeping a head's K / V in one L2 is worth more.)
+inline int head_split(long long heads, long long per_head)
+{
+    if (heads <= 0 || heads % 8 == 0 || heads >= 64) return 1;
+    long long g = heads % 8;                         // gcd(heads, 8)
+    g = (g % 4 == 0) ? 4 : (g % 2 == 0) ? 2 : 1;
+    int f = (int)(8 / g);
+    while (f > 1 && f > per_head) f /= 2;            // never more virtual heads than blocks to share
+    return f;
+}
+inline long long grid_blocks(long long heads, long long per_head, int hsplit)
+{
+    const long long vheads = ((heads * hsplit + 7) / 8) * 8;
+    return vheads * ((per_head + hsplit - 1) / hsplit);
+}
+
 // One-time, PER-DEVICE opt-in of a kernel to more than 64 KiB of dynamic LDS (the attribute belongs to the function on
 // the current device: a process that drives several GPUs needs it on each).  KernelTag gives every kernel instantiation
 // its own flags; lock-free on the fast path, and harmless if two threads race to set the same attribute.

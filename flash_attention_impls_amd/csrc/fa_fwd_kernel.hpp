@@ -52,6 +52,7 @@ struct FwdParams {
                              // Q / K / V row are read as zeros (buffer offsets pushed out of range) and not stored in O
     int nqb;                 // ceil(S / 256)
     int unpaired;            // causal launches only: 1 = one query block per workgroup (small grids), 0 = block pairs
+    int hsplit;              // virtual heads per head of the grid mapping (wg_decode): 1 unless B*H is small and not a multiple of 8
     int bh;                  // B*H
     // element strides (innermost head_dim stride is 1)
     long long q_sb, q_sh, q_ss;
@@ -64,6 +65,22 @@ struct FwdParams {
 };
 
 template <class To, class From> __device__ __forceinline__ To bitcast(From f) { return __builtin_bit_cast(To, f); }
+
+// Workgroup -> (head, block of the head).  blockIdx % 8 is the XCD a workgroup lands on (round-robin dispatch), and all
+// blocks of a (batch, head) slice go to one XCD, so that its K / V stay in that XCD's L2: head = 8 * (slot / per_head) +
+// xcd.  With a head count that is not a multiple of 8 that leaves XCDs idle (4 heads: half the chip); the host then
+// sets hsplit = 2, 4 or 8 virtual heads per head (heads * hsplit a multiple of 8), virtual head r of a head owning its
+// blocks t = r, r + hsplit, ...  Returns false for the padding workgroups of the grid.
+__device__ __forceinline__ bool wg_decode(int bid, int heads, int per_head, int hsplit, int& head, int& t)
+{
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int pvh = (per_head + hsplit - 1) / hsplit;           // blocks per virtual head
+    const int hl = slot / pvh;
+    const int vhead = hl * 8 + xcd;
+    head = vhead / hsplit;
+    t = (slot - hl * pvh) * hsplit + (vhead - head * hsplit);
+    return head < heads && t < per_head;
+}
 
 // kPBias : log2 offset added to the softmax reference so that P = exp2(score - ref) starts at 2^-kPBias and has
 //          room to grow while the reference stays fixed (fp16 P saturates at 65504; bf16 has the fp32 range).
@@ -258,17 +275,12 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     // head share an XCD (its L2 holds that head's K/V).  Causal: a workgroup processes the pair of query
     // blocks (nqb-1-t, t) one after the other, so every workgroup carries the same number of key tiles
     // (nqb+1 of them) and the grid is balanced however the dispatcher places it.
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int slot = bid >> 3;
     // causal: a workgroup takes the query-block pair (nqb-1-t, t) -- equal work for every workgroup -- unless the launch is
     // so small that every query block can have a CU of its own (p.unpaired: then the longest block alone sets the time)
     const bool paired = CAUSAL && !p.unpaired;
     const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
-    const int hl = slot / wg_per_head;
-    const int tq = slot - hl * wg_per_head;
-    const int head = hl * 8 + xcd;
-    if (head >= p.bh) return;
+    int head, tq;
+    if (!wg_decode(blockIdx.x, p.bh, wg_per_head, p.hsplit, head, tq)) return;
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;

@@ -76,17 +76,12 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- workgroup -> (head, query block(s)): see fa_fwd_kernel.hpp
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int slot = bid >> 3;
     // causal: a workgroup takes the query-block pair (nqb-1-t, t) -- equal work for every workgroup -- unless the launch is
     // so small that every query block can have a CU of its own (p.unpaired: then the longest block alone sets the time)
     const bool paired = CAUSAL && !p.unpaired;
     const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
-    const int hl = slot / wg_per_head;
-    const int tq = slot - hl * wg_per_head;
-    const int head = hl * 8 + xcd;
-    if (head >= p.bh) return;
+    int head, tq;
+    if (!wg_decode(blockIdx.x, p.bh, wg_per_head, p.hsplit, head, tq)) return;
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;                         // query rows

@@ -379,3 +379,35 @@ def test_bwd_large_logits(dt, mul):
         got = got.float().cpu().numpy().astype(np.float64)
         assert np.isfinite(got).all(), key
         assert np.abs(got - r).max() <= 2 * TOL[dt] * max(1.0, np.abs(r).max()), (key, np.abs(got - r).max(), np.abs(r).max())
+
+
+def test_bwd_query_range_split_for_small_grids():
+    """Few (batch, head) slices and a long sequence: the dK/dV kernel splits the visible query range of every key block
+    over several workgroups (fp32 partial sums + reduction pass) when the workspace has room for them
+    (fa_bwd_ex_workspace_bytes); with the smaller fa_bwd_workspace_bytes one workgroup per key block does it all.
+    Both against the float64 oracle, and against each other."""
+    import importlib
+    host = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    lib = fa.load_library()
+    B, H, S, D = 1, 2, 4096, 64
+    q, k, v, do = rand4(B, H, S, D, torch.bfloat16, seed=77)
+    scale = D ** -0.5
+    for causal in (True, False):
+        o, lse = host._fwd_raw(lib, q, k, v, causal, scale, None, True)
+        small, big = lib.fa_bwd_workspace_bytes(B, H, S), lib.fa_bwd_ex_workspace_bytes(B, H, H, S, S, D)
+        assert big > small
+        outs = {}
+        for name, nbytes in (("unsplit", small), ("split", big)):
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                               dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, H, S, S, D, *([None] * 8),
+                               0, int(causal), scale, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, lib.fa_last_error()
+            torch.cuda.synchronize()
+            outs[name] = (dq, dk, dv)
+        ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=causal)
+        assert torch.equal(outs["split"][0], outs["unsplit"][0])
+        for name in outs:
+            for got, r, key in zip(outs[name], ref[:3], ("dq", "dk", "dv")):
+                assert_grad_close(got, r, "bf16", f"{name} causal={causal}:{key}")
