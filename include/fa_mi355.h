@@ -148,13 +148,15 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
  *          see no key: their O rows are 0, their LSE -inf, and they contribute no gradient.
  * Everything else is as in the entry point of the same name; the strides of K, V, dK, dV address [B, H_kv, S_k, D]
  * tensors (NULL = contiguous).  dK and dV are the sums over the query heads of the group, accumulated in registers by
- * one workgroup per (key block, key/value head): still no atomics, no zero-fill, bitwise deterministic.
+ * one workgroup per (key block, key/value head) -- or, for small launches, by a few of them whose fp32 partial sums a
+ * reduction pass adds in a fixed order: no atomics, no zero-fill, run-to-run deterministic either way.
  * H_kv == H and S_k == S_q is exactly fa_fwd / fa_fwd_fp8 / fa_bwd.
  * Workspaces: fa_fp8_workspace_bytes(B, H, max(S_q, S_k), D) and fa_bwd_workspace_bytes(B, H, S_q) are sufficient.
- * fa_bwd_ex_workspace_bytes is the recommended size for fa_bwd_ex: with few key/value heads and a small batch (multi-query
- * attention above all) it adds room for fp32 partial sums, so that the query heads of a group can be split over several
- * dK/dV workgroups and summed by a reduction pass (same results up to fp32 summation order, still deterministic); with
- * the smaller fa_bwd_workspace_bytes the unsplit kernel runs.
+ * fa_bwd_ex_workspace_bytes is the recommended size for fa_bwd_ex (and fa_bwd): where a launch would have too few dK/dV
+ * workgroups for the chip -- few key/value heads and a small batch, multi-query attention above all; or fewer workgroups
+ * than CUs -- it adds room for fp32 partial sums, so that the query heads of a group (or the query range of a key block)
+ * can be split over several workgroups and summed by a reduction pass (same results up to fp32 summation order); with the
+ * smaller fa_bwd_workspace_bytes the unsplit kernel runs.
  */
 size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D);
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
