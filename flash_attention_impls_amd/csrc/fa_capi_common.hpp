@@ -30,13 +30,16 @@ inline bool set_strides(const int64_t* s, int H, int S, int D, long long& sb, lo
 // Grid mapping shared by all kernels (wg_decode in fa_fwd_kernel.hpp): blockIdx % 8 = XCD, all blocks of a (batch, head)
 // slice on one XCD.  A head count that is small and not a multiple of 8 would leave XCDs idle (4 heads: half the chip):
 // each head then becomes 2, 4 or 8 virtual heads that share its blocks, so that the virtual heads fill all 8 XCDs evenly.
-// (From 64 heads on the idle share is below 10 % and keeping a head's K / V in one L2 is worth more.)
 inline int head_split(long long heads, long long per_head)
 {
-    if (heads <= 0 || heads % 8 == 0 || heads >= 64) return 1;
-    long long g = heads % 8;                         // gcd(heads, 8)
-    g = (g % 4 == 0) ? 4 : (g % 2 == 0) ? 2 : 1;
-    int f = (int)(8 / g);
+    if (heads <= 0) return 1;
+    // the smallest split that leaves at most 10 % of the (virtual head, XCD) slots empty: every doubling also doubles
+    // the number of L2s a head's K / V are fetched into
+    int f = 1;
+    for (; f < 8; f *= 2) {
+        const long long v = heads * f, slots = ((v + 7) / 8) * 8;
+        if ((slots - v) * 10 <= slots) break;
+    }
     while (f > 1 && f > per_head) f /= 2;            // never more virtual heads than blocks to share
     return f;
 }
