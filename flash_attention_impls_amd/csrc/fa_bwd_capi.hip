@@ -279,9 +279,9 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     pk.o2_sb = st[7][0]; pk.o2_sh = st[7][1]; pk.o2_ss = st[7][2];
     pk.nxb = (S_k + 32 * fa::bwd_waves<1>() - 1) / (32 * fa::bwd_waves<1>());
 
-    // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp), unless every block can
-    // have one of the 256 CUs to itself
-    pq.unpaired = (causal != 0 && pq.nxb > 1 && (((long long)B * H + 7) / 8) * 8 * pq.nxb <= 256) ? 1 : 0;
+    // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp), unless single blocks are
+    // expected to finish earlier (fa_capi::causal_unpaired)
+    pq.unpaired = (causal != 0 && fa_capi::causal_unpaired((long long)B * H, pq.nxb)) ? 1 : 0;
     pq.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);
     pk.hsplit = fa_capi::head_split((long long)pk.bh, pk.nxb);
     const int grid_q = bwd_grid((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);

@@ -127,13 +127,12 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
     }
 }
 
-// causal launches pair query blocks (nqb-1-t, t) per workgroup for equal work -- unless every query block can have one
-// of the 256 CUs to itself: then the longest block alone sets the time, one block less than a pair
+// causal launches pair query blocks (nqb-1-t, t) per workgroup for equal work -- unless single blocks, longest first, are
+// expected to finish earlier (fa_capi::causal_unpaired: small grids, or a mostly empty last round of pairs)
 bool unpaired_for(int B, int H, int S, bool causal)
 {
-    const long long heads = (((long long)B * H + 7) / 8) * 8;
     const long long nqb = (S + fa::kBM - 1) / fa::kBM;
-    return causal && nqb > 1 && heads * nqb <= 256;
+    return causal && fa_capi::causal_unpaired((long long)B * H, nqb);
 }
 
 int grid_for(int B, int H, int S, bool causal)

@@ -1,6 +1,7 @@
 // Shared by the C-ABI translation units: per-thread error message and stride decoding.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdint>
@@ -47,6 +48,20 @@ inline long long grid_blocks(long long heads, long long per_head, int hsplit)
 {
     const long long vheads = ((heads * hsplit + 7) / 8) * 8;
     return vheads * ((per_head + hsplit - 1) / hsplit);
+}
+
+// Causal launches: pair the blocks of a head (nb-1-t, t) into workgroups of equal work, or launch them one by one, longest
+// first?  Pairs are perfectly balanced but quantised: G workgroups on 256 CUs take ceil(G / 256) rounds of nb + 1 block
+// units.  Single blocks take about max(nb, total work / 256) with some slack for the greedy order.  Returns true when the
+// single-block launch is expected to finish first (small grids, and grids whose last round of pairs would be mostly empty).
+inline bool causal_unpaired(long long heads, long long nb)
+{
+    if (nb <= 1) return false;
+    const long long pairs = heads * ((nb + 1) / 2);
+    const double t_pair = (double)((pairs + 255) / 256) * (double)(nb + 1);
+    const double work = (double)heads * (double)nb * (double)(nb + 1) / 2.0;
+    const double t_single = std::max((double)nb, 1.2 * work / 256.0);
+    return t_single < 0.85 * t_pair;                 // (measured: at equal estimates the pairs win, the greedy order is no LPT)
 }
 
 // One-time, PER-DEVICE opt-in of a kernel to more than 64 KiB of dynamic LDS (the attribute belongs to the function on
