@@ -1,4 +1,4 @@
-"""Bench helpers mirroring the reference harness (code/triton_fa2/FA2-triton.py:249-268)."""
+"""Bench helpers: this build's event-timing loop, the FLOP / byte model and the reference harness' max-batch probe."""
 from __future__ import annotations
 
 import statistics
@@ -6,23 +6,40 @@ import statistics
 import torch
 
 
-def measure_latency(func, warmup: int = 10, iters: int = 100):
-    """Per-iteration event timing with a sync after every call, like the reference's
-    ``measure_latency`` (:249-268): returns mean/std (population)/min in ms."""
+def time_launches(func, warmup: int = 10, iters: int = 100, sync_each: bool = False):
+    """GPU time of `iters` calls of `func`, one HIP event between consecutive calls on the current stream (iters + 1
+    events, read back after ONE final synchronisation, so the stream stays full and a call's host cost hides behind the
+    previous call's kernel).  Returns mean / population std / min / median / max in ms.
+    `sync_each=True` drains the stream after every call instead -- the reference harness' rule (`measure_latency`,
+    code/triton_fa2/FA2-triton.py:249-268: a sync per iteration), which adds the launch latency of an idle stream to each
+    sample; the reports that quote the reference's semantics use it."""
     for _ in range(warmup):
         func()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    if sync_each:
+        times = []
+        for i in range(iters):
+            marks[i].record()
+            func()
+            marks[i + 1].record()
+            marks[i + 1].synchronize()
+            times.append(marks[i].elapsed_time(marks[i + 1]))
+    else:
+        marks[0].record()
+        for i in range(iters):
+            func()
+            marks[i + 1].record()
         torch.cuda.synchronize()
-    times = []
-    start = torch.cuda.Event(enable_timing=True)
-    end = torch.cuda.Event(enable_timing=True)
-    for _ in range(iters):
-        start.record()
-        func()
-        end.record()
-        torch.cuda.synchronize()
-        times.append(start.elapsed_time(end))
-    return {"mean_ms": statistics.mean(times), "std_ms": statistics.pstdev(times),
-            "min_ms": min(times), "iters": iters}
+        times = [marks[i].elapsed_time(marks[i + 1]) for i in range(iters)]
+    ts = sorted(times)
+    return {"mean_ms": statistics.fmean(times), "std_ms": statistics.pstdev(times), "min_ms": ts[0],
+            "median_ms": ts[len(ts) // 2], "max_ms": ts[-1], "iters": iters}
+
+
+def measure_latency(func, warmup: int = 10, iters: int = 100):
+    """The reference harness' name and call shape (FA2-triton.py:249): its per-iteration-sync rule on this build's timing loop."""
+    return time_launches(func, warmup, iters, sync_each=True)
 
 
 def attn_flops(B: int, H: int, S: int, D: int, causal: bool) -> float:

@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256) void fa_bwd_reduce_kernel(const float* __restr
     *reinterpret_cast<u32x4*>(dst) = w;
 }
 
-// (head_dim 64, MODE 0, non-causal: 128 VGPRs and 48 KiB of LDS let two workgroups share a CU: +3 %; the causal variant
-// spills at 128 registers and loses 6 %, so it keeps 256)
+// (MODE 0 keeps the 256-register budget at every head_dim.  Round 1 ran the head_dim-64 non-causal variant within 128 VGPRs --
+// two workgroups per CU, +3 % -- but that build spilled 1-6 registers to scratch whatever was moved around; a scratch reload
+// behind the hand-counted LDS-DMA waits drains the staging ring, and no default-path kernel may have a private segment.)
 template <class T, int D, int MODE, bool CAUSAL>
-__global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !CAUSAL) ? 4 : (MODE == 0 ? 2 : 1)) void fa_bwd_kernel(const BwdParams p)
+__global__ __launch_bounds__(64 * bwd_waves<MODE>(), MODE == 0 ? 2 : 1) void fa_bwd_kernel(const BwdParams p)
 {
     constexpr int NW = bwd_waves<MODE>();
     constexpr int XB = NW * 32;                // stationary rows per workgroup
@@ -185,7 +186,6 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int lane = tid & 63;
 
     // workgroup -> (head, stationary block); blockIdx % 8 = XCD: all blocks of a head share one L2
     // MODE 0 under the causal mask: a workgroup takes the query-block pair (nxb-1-t, t), so that every workgroup
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
   for (int pass = 0; pass < n_pass; ++pass) {
     const int xb = PAIRABLE ? (pass == 0 ? p.nxb - 1 - t : t) : t;      // (unpaired: one pass, longest blocks first)
     const int x0 = xb * XB;                    // first stationary row of the workgroup
-    asm volatile("" : "+v"(lane));             // per-pass opaque lane id: nothing derived from it is hoisted out of the pass loop
+    const int lane = lane_here();              // per-pass opaque lane id: nothing derived from it is hoisted out of the pass loop
     const int li = lane & 15;
     const int lg = lane >> 4;
     // MODE 0 under the causal mask: waves w and w+4 share a SIMD; row blocks that sum to 7 give every SIMD the same
@@ -341,18 +341,23 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     // ---- LDS read addresses (stage 0, block 0)
     // (ring stage, block and tile offsets are added as instruction immediates: < 64 KiB per ring)
     unsigned ra[KS], ra2[KS];  // row reads: lane (li, lg) reads row li (+16 yt + 32 blk), chunk 4 ks + lg
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        ra[ks] = lds_base + li * ROWB + bwd_swz<D>(li, 4 * ks + lg) * 16;
-        ra2[ks] = ra[ks] + Y2BASE;
-        asm volatile("" : "+v"(ra2[ks]));                   // opaque: keeps it a register of its own (the sum would not fit an immediate)
-    }
-    unsigned sta = lds_base + STBASE + lg * 16;            // statistics of rows 4 lg .. +3 (+16 yt + 32 blk)
-    asm volatile("" : "+v"(sta));
+    unsigned sta;              // statistics of rows 4 lg .. +3 (+16 yt + 32 blk)
     unsigned ta[DT], ta2[MODE == 1 ? DT : 1];   // transposed reads: lane 4 qq + pp of a 16-lane group supplies row 4 lg + qq, columns 16 dt + 4 pp .. +3
-    {
-        const int qq = li >> 2, pp = li & 3;
-        const int row = 4 * lg + qq;                  // + 16 a + 32 blk: multiples of 16 rows, swizzle-neutral
+    // (filled in behind the prologue's DMA issue, from fresh lane coordinates: the address arithmetic then starts where the
+    // stationary fragments' load registers are free again, instead of being carried -- spilled -- across them)
+    auto setup_addresses = [&]() {
+        const int lane_a = lane_here();
+        const int li_a = lane_a & 15, lg_a = lane_a >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ra[ks] = lds_base + li_a * ROWB + bwd_swz<D>(li_a, 4 * ks + lg_a) * 16;
+            ra2[ks] = ra[ks] + Y2BASE;
+            asm volatile("" : "+v"(ra2[ks]));                   // opaque: keeps it a register of its own (the sum would not fit an immediate)
+        }
+        sta = lds_base + STBASE + lg_a * 16;
+        asm volatile("" : "+v"(sta));
+        const int qq = li_a >> 2, pp = li_a & 3;
+        const int row = 4 * lg_a + qq;                  // + 16 a + 32 blk: multiples of 16 rows, swizzle-neutral
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             ta[dt] = lds_base + row * ROWB + bwd_swz<D>(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
                 asm volatile("" : "+v"(ta2[dt]));
             }
         }
-    }
+    };
 
     f32x4 acc1[DT][2];         // MODE 0: dQ^T ; MODE 1: dK^T   [head_dim tile][x tile]
     f32x4 acc2[MODE == 1 ? DT : 1][2];   // MODE 1: dV^T
@@ -504,6 +509,7 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
         }
         issue_tile(j_begin, stage);
         issue_tile(j_begin + 1, (stage + 1) % NS);
+        setup_addresses();
         if constexpr (!PIPE) {
             // two waves per SIMD: the hardware interleaves one wave's matrix steps with its partner's softmax
             auto sync_and_issue0 = [&](int j, int dst_stage) {
@@ -631,6 +637,8 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), (MODE == 0 && D == 64 && !C
     // ---- epilogue: out[x][16 dt + 4 lg + 0..3] = acc[dt][xt] * mult, 16-byte stores through v_permlane16_swap pairs
     auto store_out = [&] __device__ (f32x4 (&acc)[DT][2], void* out, long long sb, long long sh, long long ss, float mult) {
         elem_t* oh = reinterpret_cast<elem_t*>(out) + b * sb + h * sh;
+        const int lane_e = lane_here();               // fresh lane coordinates (not kept alive across the main loop)
+        const int li = lane_e & 15, lg = lane_e >> 4;
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
             const int xrow = x0w + 16 * xt + li;

@@ -85,14 +85,23 @@ int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
     // default: the 16x16x32 kernel; -DFA_MFMA32 (and the FA_QB variants) select the 32x32x16 kernel of fa_fwd_kernel.hpp
 #if !defined(FA_MFMA32)
     if constexpr (kQB == 1) {
-        // head_dim 64: the 16x16 kernel fits two workgroups per CU (128 VGPRs, 64 KiB of LDS: +11-12 % at cfg3's
-        // batch and sequence); launches that do not fill the chip twice (cfg2: 128 workgroups) are latency-bound and
-        // 5 % faster on the 32x32 kernel
-        if (D == 128 || grid > 512)
+        // head_dim 128: always the 16x16 kernel (the 32x32 kernel is then not even instantiated)
+        if constexpr (D == 128) {
             return causal ? launch16<T, true, D>(p, grid, s) : launch16<T, false, D>(p, grid, s);
+        } else {
+            // head_dim 64: the 16x16 kernel fits two workgroups per CU (128 VGPRs, 64 KiB of LDS: +11-12 % at cfg3's
+            // batch and sequence); launches that do not fill the chip twice (cfg2: 128 workgroups) are latency-bound and
+            // 5 % faster on the 32x32 kernel
+            if (grid > 512)
+                return causal ? launch16<T, true, D>(p, grid, s) : launch16<T, false, D>(p, grid, s);
+            return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
+        }
+    } else {
+        return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
     }
-#endif
+#else
     return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
+#endif
 }
 
 // fp8 (OCP e4m3fn) -> bf16, exact (every e4m3 value is representable in bf16).  HBM-bound streaming pass:

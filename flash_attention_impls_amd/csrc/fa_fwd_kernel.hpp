@@ -248,6 +248,15 @@ __device__ __forceinline__ void asm_mfma_bf16_acc(f32x16& d, u32x4 a, u32x4 b) {
 
 template <int V> using IC = std::integral_constant<int, V>;
 
+// This lane's index (0..63), produced in place by an opaque instruction pair.  Nothing derived from it can be hoisted
+// above the call, so lane coordinates needed again after a long loop (epilogue, fallback) are recomputed there instead of
+// being kept alive -- i.e. spilled -- across it, and threadIdx.x need not stay live past the kernel's first lines.
+__device__ __forceinline__ int lane_here() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 struct SmState {
     f32x16 sv;        // (masked) scores of one 32-key block
     float rs0, rs1;   // this lane's partial row sums (two independent chains)

@@ -53,12 +53,17 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     constexpr int D = DD;                      // compiled head_dim: 128 or 64
     static_assert(D == 128 || (D == 64 && !QK8), "head_dim 64 has no fp8 Q/K variant");
     constexpr int NG = D / 64;                 // groups of four head_dim tiles in the P V product
+    constexpr int VG = 4;
     constexpr int NWAVES = 8;
 #if defined(FA_DMA_SPREAD) && FA_DMA_SPREAD == 0
     constexpr bool SPREAD = false;
 #else
     constexpr bool SPREAD = DD == 128;         // (see FA_SYNC_STAGE below)
 #endif
+    // head_dim 64 runs two workgroups per CU within 128 VGPRs (four waves per SIMD): there the block loop is NOT software
+    // pipelined inside a wave (S(n), softmax(n), P V(n) in program order: one S^T and one P^T register set instead of two --
+    // the pipelined form needs ~134 registers and spilled), the other three waves of the SIMD fill the gaps
+    constexpr bool LEAN = DD == 64;
     constexpr int QKB = QK8 ? 1 : 2;           // bytes per Q / K element
     constexpr int KROWB = D * QKB;             // bytes per K row in LDS
     constexpr int CPTK = kBN * KROWB / 1024 / NWAVES;   // K DMA pieces per wave per tile (2, fp8: 1)
@@ -109,8 +114,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
   for (int pass = 0; pass < n_pass; ++pass) {
     const int qb = CAUSAL ? ((pass == 0) ? p.nqb - 1 - tq : tq) : tq;      // (unpaired: one pass, longest blocks first)
     // lane coordinates, opaque per pass (keeps derived values from being hoisted out of the pass loop and spilled)
-    int lane = tid & 63;
-    asm volatile("" : "+v"(lane));
+    const int lane = lane_here();
     const int li = lane & 15;
     const int lg = lane >> 4;
 
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
-    auto load_q = [&](int qblk) {
+    auto load_q = [&](int qblk, int lane_q) {     // (lane coordinates passed in: the call behind the main loop brings fresh ones)
+        const int li = lane_q & 15, lg = lane_q >> 4;
         const int row0 = qblk * kBM + rowblk_of_wave * 32;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             }
         }
     };
-    if (pass == 0) load_q(qb);
+    if (pass == 0) load_q(qb, lane);
 
     // ---- K/V staging by LDS-DMA (see fa_fwd_kernel.hpp); V uses the 16x16 swizzle
     constexpr int VBASE = kStages * TILE;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     // fragment registers: one group of 4 K fragments, one group of 4 V^T fragments (re-read one group ahead)
     u32x4 kf[QK8 ? 1 : 4];
     u32x2 kf8[QK8 ? 4 : 1];
-    u32x4 vf[4];
+    u32x4 vf[VG];
     // stage_c >= 0: the address registers hold stage-0 bases and the ring stage is an immediate (unrolled loop);
     // stage_c == -1: the address registers already carry the stage of the tile being read
     auto read_kgroup = [&] __device__ (auto stage_c, auto half_c, auto kt_c) {
@@ -225,9 +230,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         constexpr int stage = decltype(stage_c)::value, half = decltype(half_c)::value, grp = decltype(grp_c)::value;
         constexpr int off = (stage < 0 ? 0 : stage * TILE) + (32 * half) * ROWB;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            u32x2 lo = lds_read_tr16_b64(va[4 * grp + d] + off);
-            u32x2 hi = lds_read_tr16_b64(va[4 * grp + d] + off + 16 * ROWB);
+        for (int d = 0; d < VG; ++d) {
+            u32x2 lo = lds_read_tr16_b64(va[VG * grp + d] + off);
+            u32x2 hi = lds_read_tr16_b64(va[VG * grp + d] + off + 16 * ROWB);
             vf[d] = u32x4{lo[0], lo[1], hi[0], hi[1]};
         }
     };
@@ -303,10 +308,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     auto mfma_pv = [&] __device__ (auto par_c, auto grp_c) {
         constexpr int par = decltype(par_c)::value, grp = decltype(grp_c)::value;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < VG; ++d)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
-                o_acc[4 * grp + d][qt] = T::mfma16(vf[d], pf[par][qt], o_acc[4 * grp + d][qt]);
+                o_acc[VG * grp + d][qt] = T::mfma16(vf[d], pf[par][qt], o_acc[VG * grp + d][qt]);
     };
     auto mfma_s = [&] __device__ (auto par_c, auto kt_c) {
         constexpr int par = decltype(par_c)::value, kt = decltype(kt_c)::value;
@@ -465,11 +470,14 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         dma_k(0, 0);
         dma_v(0, 0);
         dma_k(1, TILE);
+        if constexpr (LEAN) dma_v(1, TILE);    // (lean loop: block n reads V of its own tile, so V runs as far ahead as K)
         dma_k(2, 2 * TILE);
-        dma_v(1, TILE);
+        if constexpr (LEAN) dma_v(2, 2 * TILE);
+        else dma_v(1, TILE);
     };
     if (pass == 0) issue_prologue();
-    dma_wait<2 * CPTK + CPT>(); // this wave's pieces of K(0), V(0) have landed ...
+    if constexpr (LEAN) dma_wait<2 * (CPTK + CPT)>();
+    else dma_wait<2 * CPTK + CPT>(); // this wave's pieces of K(0), V(0) have landed ...
     __syncthreads();            // ... and every wave's are visible
 
     int dk = 0, dv = 0;                            // address deltas used by the odd block of iteration j
@@ -486,7 +494,8 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 #endif
 #if !defined(FA_ABL_NODMA)
         dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
-        dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+        if constexpr (LEAN) dma_v(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
+        else dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
 #endif
     };
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
@@ -521,6 +530,66 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 #define FA_SYNC_STAGE(j) do { if constexpr (SPREAD) sync_only(); else sync_and_stage(j); } while (0)
 #define FA_SYNC_STAGE_C(st, j) do { if constexpr (SPREAD) sync_only(); else sync_and_stage_c(st, j); } while (0)
 #define FA_ODD_BLOCK(...) do { if constexpr (SPREAD) block_s(__VA_ARGS__); else block(__VA_ARGS__); } while (0)
+    if constexpr (LEAN) {
+        // ---- lean loop (head_dim 64): per 32-key block  S(n) -> softmax(n) -> P V(n), nothing carried between blocks but
+        // O, the row sums and the reference; K and V fragments of a block are read in front of their products (the V
+        // reads are issued before the softmax and land behind it)
+        const int mbl = min(CAUSAL ? (max(0, q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block that needs the mask
+        auto block_lean = [&] __device__ (auto half_c, auto mask_c, auto first_c, int n) {
+            constexpr int HALF = decltype(half_c)::value;
+            constexpr bool FIRST = decltype(first_c)::value;
+            typedef IC<0> P0;
+            const int key0 = n * 32;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                if (kt == 0) read_kgroup(IC<-1>{}, IC<HALF>{}, IC<0>{});
+                else read_kgroup(IC<-1>{}, IC<HALF>{}, IC<1>{});
+                if (kt == 0) mfma_s(P0{}, IC<0>{});
+                else mfma_s(P0{}, IC<1>{});
+            }
+            read_vgroup(IC<-1>{}, IC<HALF>{}, IC<0>{});
+            if constexpr (FIRST) sm_set_reference(mask_c, P0{}, key0);
+            sm_slice(mask_c, P0{}, IC<0>{}, IC<0>{}, key0);
+            sm_slice(mask_c, P0{}, IC<0>{}, IC<1>{}, key0);
+            sm_slice(mask_c, P0{}, IC<1>{}, IC<0>{}, key0);
+            sm_slice(mask_c, P0{}, IC<1>{}, IC<1>{}, key0);
+            mfma_pv(P0{}, IC<0>{});
+        };
+        typedef std::true_type Y;
+        typedef std::false_type N;
+        int j = 0;
+        const int NT = my_nt;
+        if (NT > 0) {
+            // tile 0: its first block fixes the reference
+            if (0 >= mbl) block_lean(IC<0>{}, Y{}, Y{}, 0); else block_lean(IC<0>{}, N{}, Y{}, 0);
+            sync_and_stage(0);
+            if (1 >= mbl) block_lean(IC<1>{}, Y{}, N{}, 1); else block_lean(IC<1>{}, N{}, N{}, 1);
+            advance(TILE, TILE);
+            end_iter();
+            j = 1;
+            const int ju = min(NT, mbl >> 1);          // tiles whose two blocks need no mask
+            for (; j < ju; ++j) {
+                block_lean(IC<0>{}, N{}, N{}, 2 * j);
+                sync_and_stage(j);
+                block_lean(IC<1>{}, N{}, N{}, 2 * j + 1);
+                const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
+                advance(d, d);
+                end_iter();
+            }
+            for (; j < NT; ++j) {
+                block_lean(IC<0>{}, Y{}, N{}, 2 * j);
+                sync_and_stage(j);
+                block_lean(IC<1>{}, Y{}, N{}, 2 * j + 1);
+                const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
+                advance(d, d);
+                end_iter();
+            }
+        }
+        for (; j < nt; ++j) {                          // remaining tiles of the workgroup: staging duty only
+            sync_and_stage(j);
+            end_iter();
+        }
+    } else {
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block whose softmax needs the mask
     const int jm = (mb + 1) >> 1;                  // iteration j softmaxes blocks 2j-1 and 2j
@@ -589,6 +658,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         sync_and_stage(j);
         end_iter();
     }
+    }  // !LEAN
 
     // ---- exact fallback (rare): plain per-tile online softmax with running max and rescale
     // A lane's row-sum share below kPLimit bounds every P it produced (all terms are positive); NaN fails the test.
@@ -596,8 +666,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     dma_wait<0>();                                 // no DMA may still be writing LDS past this point
     // (flag words in the last V stage: the next pass's prologue does not write there, and its first later DMA sits
     // behind a barrier)
-    if (wg_any(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit), lds_base + VBASE + (kStages - 1) * TILE, wave, tid & 63, NWAVES)) {
+    if (wg_any(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
         constexpr int KO = 0, VO = VBASE;                     // two stages each: K at KO, V at VO
+        const int lane = lane_here();                         // (fresh lane coordinates: see lane_here)
+        const int li = lane & 15, lg = lane >> 4;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -703,12 +775,14 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     // ---- the next query block of a causal pair travels while this block's output is normalised and stored
     if (pass + 1 < n_pass) {
         issue_prologue();
-        load_q(tq);
+        load_q(tq, lane_here());
     }
 
     // ---- epilogue: combine the four lane groups' row sums, normalise, store O (and LSE)
+    const int lane_e = lane_here();                // (fresh lane coordinates: see lane_here)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+        const int li = lane_e & 15, lg = lane_e >> 4;
         float l = l_part[qt];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);

@@ -5,6 +5,10 @@ RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo" in CPU tests).
 The reference has no distributed code at all; each (b, h) is an independent
 problem exactly as in its grid (code/triton_fa2/FA2-triton.py:40-43), which is what makes
 the split exact: the gathered O is bitwise the single-GPU O.
+
+With grouped key/value heads (``k``, ``v`` with H_kv < H heads) the independent unit is a (batch, key/value head)
+pair together with the G = H / H_kv query heads that read it: the split runs over those B * H_kv units, so that a
+rank's queries always find their keys and values in the rank's own shard.
 """
 from __future__ import annotations
 
@@ -15,8 +19,7 @@ import torch.distributed as dist
 
 
 def shard_bounds(units: int, rank: int, world: int) -> tuple[int, int]:
-    """Contiguous [lo, hi) slice of ``units`` (= B*H) owned by ``rank``; the first
-    ``units % world`` ranks get one extra unit."""
+    """Contiguous [lo, hi) slice of ``units`` owned by ``rank``; the first ``units % world`` ranks get one extra unit."""
     if world <= 0 or not (0 <= rank < world):
         raise ValueError(f"bad rank/world {rank}/{world}")
     base, rem = divmod(units, world)
@@ -25,26 +28,41 @@ def shard_bounds(units: int, rank: int, world: int) -> tuple[int, int]:
     return lo, hi
 
 
-def local_shard(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
-    """View of the (B,H,S,D) tensor's units owned by ``rank`` as (n,1,S,D)."""
+def local_shard(t: torch.Tensor, rank: int, world: int, group: int = 1) -> torch.Tensor:
+    """The units of a (B, H, S, D) tensor owned by ``rank`` as (n, group, S, D): a unit is ``group`` consecutive
+    heads of one batch (group = 1 for keys / values, G = H / H_kv for the queries of a grouped-query layout).
+    A view whenever the (batch, head) axes can be flattened in place; otherwise only the rank's own units are copied
+    (never the whole tensor: slice first, then make contiguous)."""
     B, H, S, D = t.shape
-    lo, hi = shard_bounds(B * H, rank, world)
-    return t.reshape(B * H, 1, S, D)[lo:hi]
+    if group <= 0 or H % group != 0:
+        raise ValueError(f"{H} heads are not a multiple of the unit size {group}")
+    hu = H // group
+    lo, hi = shard_bounds(B * hu, rank, world)
+    tu = t.unflatten(1, (hu, group))                     # (B, hu, group, S, D), always a view
+    try:
+        return tu.view(B * hu, group, S, D)[lo:hi]
+    except RuntimeError:                                 # (batch, head) strides do not flatten (e.g. a (B,S,H,D) buffer)
+        parts = []
+        for b in range(lo // hu, (hi + hu - 1) // hu if hi > lo else lo // hu):
+            u0, u1 = max(lo, b * hu) - b * hu, min(hi, (b + 1) * hu) - b * hu
+            parts.append(tu[b, u0:u1])
+        if not parts:
+            return t.new_empty((0, group, S, D))
+        return torch.cat(parts, dim=0)
 
 
 def gather_output(o_local: torch.Tensor, units: int, group=None) -> torch.Tensor:
-    """All-gather the per-rank (n_r,1,S,D) outputs into (units,1,S,D) on every rank.
+    """All-gather the per-rank (n_r, G, S, D) outputs into (units, G, S, D) on every rank.
     Equal shards use one all_gather_into_tensor (one direct message per peer link on xGMI);
     ragged shards are padded to the largest shard and trimmed."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     n_max = -(-units // world)
-    _, _, S, D = o_local.shape
+    tail = tuple(o_local.shape[1:])
     send = o_local.contiguous()
     if send.shape[0] != n_max:
-        pad = torch.zeros((n_max - send.shape[0], 1, S, D), dtype=send.dtype, device=send.device)
+        pad = torch.zeros((n_max - send.shape[0],) + tail, dtype=send.dtype, device=send.device)
         send = torch.cat([send, pad], dim=0)
-    full = torch.empty((world * n_max, 1, S, D), dtype=send.dtype, device=send.device)
+    full = torch.empty((world * n_max,) + tail, dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(full, send, group=group)
     if units % world == 0:
         return full
@@ -52,25 +70,35 @@ def gather_output(o_local: torch.Tensor, units: int, group=None) -> torch.Tensor
     for r in range(world):
         lo, hi = shard_bounds(units, r, world)
         parts.append(full[r * n_max: r * n_max + (hi - lo)])
-    del rank
     return torch.cat(parts, dim=0)
 
 
 def flash_attn_sharded(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
-                       attn_fn: Callable | None = None, group=None, gather: bool = True):
-    """Every rank holds the full (B,H,S,D) inputs (or at least its own units); each computes
-    its contiguous slice of the B*H units and, if ``gather``, all ranks receive the full O.
+                       attn_fn: Callable | None = None, group=None, gather: bool = True,
+                       rank: int | None = None, world: int | None = None):
+    """Every rank holds the full inputs (or at least its own units); each computes its contiguous slice of the
+    B * H_kv units and, if ``gather``, all ranks receive the full (B, H, S, D) output.
 
-    ``attn_fn`` defaults to the HIP ``flash_attn``; CPU tests inject an oracle here to
-    exercise the sharding/gather logic over gloo.
+    ``attn_fn`` defaults to the HIP ``flash_attn``; CPU tests inject an oracle here to exercise the sharding/gather
+    logic over gloo.  ``rank`` / ``world`` default to the process group's; passing them (with ``gather=False``) computes
+    any rank's shard in a single process, which is how the GPU tests check the split against the unsharded launch.
     """
     if attn_fn is None:
         from .flash_attn import flash_attn as attn_fn
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
     B, H, S, D = q.shape
-    ql, kl, vl = (local_shard(t, rank, world) for t in (q, k, v))
+    Hkv = k.shape[1]
+    if v.shape[1] != Hkv or Hkv <= 0 or H % Hkv != 0:
+        raise ValueError(f"q has {H} heads, k / v have {k.shape[1]} / {v.shape[1]}: need H % H_kv == 0")
+    G = H // Hkv
+    ql = local_shard(q, rank, world, G)
+    kl, vl = local_shard(k, rank, world), local_shard(v, rank, world)
     o_local = attn_fn(ql, kl, vl, causal) if ql.shape[0] > 0 else ql.new_empty(ql.shape)
-    if not gather or world == 1:
-        return o_local if not gather else o_local.reshape(B, H, S, D)
-    return gather_output(o_local, B * H, group).reshape(B, H, S, D)
+    if not gather:
+        return o_local
+    if world == 1:
+        return o_local.reshape(B, H, S, D)
+    return gather_output(o_local, B * Hkv, group).reshape(B, H, S, D)

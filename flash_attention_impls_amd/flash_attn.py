@@ -235,10 +235,10 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     B, H, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
     dq = torch.empty_like(o)                                                        # contiguous, like o
+    if B * H * N == 0:          # no query rows: nothing flows into the keys and values (the reference zero-fills, FA2-triton.py:211-213)
+        return dq, torch.zeros((B, Hkv, Nk, D), dtype=o.dtype, device=o.device), torch.zeros((B, Hkv, Nk, D), dtype=o.dtype, device=o.device)
     dk = torch.empty((B, Hkv, Nk, D), dtype=o.dtype, device=o.device)
     dv = torch.empty_like(dk)
-    if B * H * N == 0:
-        return dq, dk, dv
     do = _kernel_ready(do.to(q.dtype))
     with torch.cuda.device(q.device), _trace_range("FA2_BWD"):
         stream = torch.cuda.current_stream().cuda_stream
@@ -285,6 +285,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     Returns O with q's dtype (fp32 inputs are computed in fp16 and cast back, like the
     reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural
     log-sum-exp of the scaled scores (the reference keeps m and l instead: lse = m + ln l).
+    ``descale`` = (q, k, v) per-tensor dequantisation scales of float8_e4m3fn inputs (rejected for other dtypes).
     Differentiable like the reference's entry point: when autograd is recording and an input requires
     grad, the HIP backward kernels produce dq, dk, dv (bf16 / fp16 / fp32-via-fp16 inputs).
     """
@@ -296,6 +297,13 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     code = _dtype_code(q.dtype)
     if needs_grad and code == FA_DTYPE_FP8_E4M3:
         raise FlashAttnArgumentError("float8 inputs are forward-only (no backward kernel)")
+    if descale is not None:
+        # per-tensor dequantisation scales belong to float8 inputs; accepting them for 16-bit inputs on one path only
+        # (the autograd Function takes none) would make the result depend on the grad mode
+        if code != FA_DTYPE_FP8_E4M3:
+            raise FlashAttnArgumentError("descale=(q, k, v scales) is only meaningful with float8_e4m3fn inputs")
+        if len(descale) != 3:
+            raise FlashAttnArgumentError("descale must hold three per-tensor scales (q, k, v)")
     lib = load_library()
     B, H, N, D_in = q.shape
     if softmax_scale is None:

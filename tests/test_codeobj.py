@@ -1,0 +1,52 @@
+"""Build-time guard on the shipped code object: no kernel of the default path may spill vector registers or own a
+private (scratch) segment.  A scratch reload sits behind an `s_waitcnt vmcnt(0)` that hipcc places itself, and that wait
+drains the hand-counted LDS-DMA ring of the attention kernels -- a silent performance loss that the
+parity tests cannot see.  Reads the gfx950 code object out of the in-tree library with the ROCm LLVM tools (CPU only)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from flash_attention_impls_amd import _build
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_notes(tmp_path):
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm LLVM tools not installed")
+    lib = shutil.copy(_build.build(), tmp_path / "lib.so")           # (the tool extracts next to its input)
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f and "gfx950" in f]
+    assert objs, "no gfx950 code object found in the library"
+    kernels = {}
+    for f in objs:
+        txt = subprocess.run([readelf, "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count:", txt)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            kernels[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
+                             for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
+    return kernels
+
+
+def test_no_kernel_spills_or_uses_scratch(tmp_path):
+    kernels = _kernel_notes(tmp_path)
+    attn = {n: k for n, k in kernels.items() if "fa_fwd" in n or "fa_bwd" in n}
+    assert len(attn) >= 20, sorted(kernels)                            # forward (16-bit, fp8) and the three backward kernels
+    bad = {n: k for n, k in attn.items() if k["vgpr_spill_count"] or k["private_segment_fixed_size"]}
+    assert not bad, f"kernels with vector spills / scratch: {bad}"
+    # scalar spills go to lanes of a VGPR (v_writelane / v_readlane), not to memory: tolerated only where listed
+    # (the wave-specialised dK/dV kernel runs two loop bodies with ~100 live scalars)
+    sbad = {n: k["sgpr_spill_count"] for n, k in attn.items() if k["sgpr_spill_count"] and "fa_bwd_dkdv_kernel" not in n}
+    assert not sbad, f"kernels with scalar spills: {sbad}"
+    assert all(k["vgpr_count"] <= 256 for n, k in attn.items() if "fa_fwd_kernel16" in n or "fa_bwd" in n)
+
+
+def test_head_dim_64_forward_fits_two_workgroups_per_cu(tmp_path):
+    """The head_dim-64 16x16 kernel is launched for two workgroups per CU: that needs <= 128 registers per lane."""
+    kernels = _kernel_notes(tmp_path)
+    d64 = {n: k for n, k in kernels.items() if "fa_fwd_kernel16" in n and "Li64E" in n}
+    assert d64 and all(k["vgpr_count"] <= 128 for k in d64.values()), d64

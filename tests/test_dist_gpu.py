@@ -1,0 +1,75 @@
+"""The sharding code on the HIP path: `dist.flash_attn_sharded` with the real kernel at world size 1,
+every rank of a W-way split emulated in one process (local_shard -> flash_attn -> concatenation) bitwise against the
+unsharded launch, a two-rank gloo rehearsal on one GPU, and `bench.py --gpus 2` started from a plain shell."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import flash_attention_impls_amd as fa  # noqa: E402
+from flash_attention_impls_amd.dist import flash_attn_sharded, local_shard, shard_bounds  # noqa: E402
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def _qkv(B, H, Hkv, S, D, dt=torch.bfloat16, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, H, S, D, generator=g).to(dt).cuda()
+    k, v = (torch.randn(B, Hkv, S, D, generator=g).to(dt).cuda() for _ in range(2))
+    return q, k, v
+
+
+@pytest.mark.parametrize("B,H,Hkv,S,D,causal", [(2, 4, 4, 512, 128, True), (1, 5, 5, 300, 128, False),
+                                                (2, 8, 2, 384, 64, True), (3, 2, 1, 260, 128, True)])
+def test_sharded_world1_and_emulated_ranks(B, H, Hkv, S, D, causal):
+    q, k, v = _qkv(B, H, Hkv, S, D)
+    ref = fa.flash_attn(q, k, v, causal)
+    assert torch.equal(flash_attn_sharded(q, k, v, causal), ref)              # world size 1, no process group
+    for W in (2, 3, 8):                                                        # (B * H_kv = 5 or 3: ragged and empty shards)
+        parts = [flash_attn_sharded(q, k, v, causal, gather=False, rank=r, world=W) for r in range(W)]
+        sizes = [p.shape[0] for p in parts]
+        assert sizes == [shard_bounds(B * Hkv, r, W)[1] - shard_bounds(B * Hkv, r, W)[0] for r in range(W)]
+        got = torch.cat(parts, dim=0).reshape(B, H, S, D)
+        assert torch.equal(got, ref), (W, sizes)
+
+
+def test_sharded_strided_inputs_copy_only_the_shard():
+    """(B,S,H,D) storage viewed as (B,H,S,D): the shard is sliced first, the kernel reads it through its strides."""
+    B, H, S, D = 2, 6, 320, 128
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(B, S, H, D, generator=g).to(torch.bfloat16).cuda().transpose(1, 2) for _ in range(3))
+    ref = fa.flash_attn(q, k, v, True)
+    parts = [flash_attn_sharded(q, k, v, True, gather=False, rank=r, world=4) for r in range(4)]
+    assert torch.equal(torch.cat(parts, dim=0).reshape(B, H, S, D), ref)
+    assert local_shard(q, 1, 4).shape == (3, 1, S, D)
+
+
+def _run(cmd, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_rank_gloo_rehearsal_on_one_gpu():
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_rehearsal_worker.py")])
+    assert res.returncode == 0 and "DIST_REHEARSAL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_bench_gpus2_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its ranks itself (before touching the GPU) and rank 0's
+    JSON line comes through.  On a one-GPU box the ranks fall back to the gloo rehearsal (all on cuda:0)."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--settle-ms", "30", "--workload", "cfg2", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env_clean, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["step_ms_min"] <= out["step_ms_median"] <= out["step_ms_max"]
