@@ -17,6 +17,7 @@
 #include "fa_capi_common.hpp"
 #include "fa_fwd_kernel.hpp"
 #include "fa_fwd_kernel16.hpp"
+#include "fa_fwd_kernel8.hpp"
 
 // 32-row query blocks per wave: 1 = 8 waves per workgroup (two per SIMD), 2 = 4 waves (one per SIMD, 512 registers)
 #ifndef FA_QB
@@ -74,6 +75,22 @@ int launch16_qk8(const fa::FwdParams& p, int grid, hipStream_t stream)
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
     hipLaunchKernelGGL((fa::fa_fwd_kernel16<fa::TypeBF16, CAUSAL, true>), dim3(grid), dim3(512), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+// head_dim > 64, fp8 Q, K and V, both products on MX-scaled fp8 MFMAs (fa_fwd_kernel8.hpp)
+template <bool CAUSAL>
+int launch8(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::kStages * 2 * fa::kBN8 * 128;
+    auto* kernel = &fa::fa_fwd_kernel8<CAUSAL>;
+    struct Tag {};
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel8<CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
@@ -267,8 +284,10 @@ size_t fa_fp8_workspace_bytes(int B, int H, int S, int D)
     if (B <= 0 || H <= 0 || S <= 0 || D <= 0) return 0;
 #if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
     const size_t copies = 3;
+#elif defined(FA_FP8_PV_BF16)
+    const size_t copies = D > 64 ? 1 : 3;               // round-1 path: only V is converted (Q, K feed fp8 MFMAs)
 #else
-    const size_t copies = D > 64 ? 1 : 3;               // head_dim > 64: only V is converted (Q, K feed fp8 MFMAs)
+    const size_t copies = D > 64 ? 0 : 3;               // head_dim > 64: nothing is converted, all three tensors feed fp8 MFMAs
 #endif
     return copies * B * H * S * D * 2;                  // bf16 copies
 }
@@ -297,21 +316,29 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     if (H_kv <= 0 || H % H_kv != 0)
         return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
     if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
-    if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_NULL_PTR, "null tensor / workspace pointer");
+    if (!q || !k || !v || !o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
+    // How the three fp8 tensors reach the matrix cores:
+    //   head_dim > 64 (default): nothing is converted; Q K^T and P V both run on MX-scaled fp8 MFMAs (fa_fwd_kernel8.hpp),
+    //                            no workspace is needed (fa_fp8_workspace_bytes = 0, `workspace` may be NULL);
+    //   head_dim <= 64, or -DFA_FP8_CONVERT_ALL: an exact fp8 -> bf16 HIP pre-pass of all three, then the bf16 kernels;
+    //   -DFA_FP8_PV_BF16 (round 1's path, kept for A/B): Q, K native on fp8 MFMAs, V converted, P V on bf16 MFMAs.
 #if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1
-    const bool native_qk = false;
+    const bool native_qk = false, native_v = false;
+#elif defined(FA_FP8_PV_BF16)
+    const bool native_qk = D > 64, native_v = false;
 #else
-    // head_dim > 64: Q and K stay fp8 and feed v_mfma_f32_16x16x32_fp8_fp8 directly (half the K bytes through HBM, L2,
-    // LDS-DMA and LDS reads); only V is converted, because P V runs on bf16 MFMAs with P from the fp32 softmax
-    const bool native_qk = D > 64;
+    const bool native_qk = D > 64, native_v = D > 64;
 #endif
     const int heads[3] = {H, H_kv, H_kv};
     const int rows[3] = {S, S_k, S_k};
     const size_t one_q = (size_t)B * H * S * D * 2, one_kv = (size_t)B * H_kv * S_k * D * 2;   // bf16 copies
-    const size_t need = native_qk ? one_kv : one_q + 2 * one_kv;
-    if (workspace_bytes < need)
-        return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
-    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
+    const size_t need = native_v ? 0 : (native_qk ? one_kv : one_q + 2 * one_kv);
+    if (need > 0) {
+        if (!workspace) return fail(FA_ERR_NULL_PTR, "null workspace pointer (%zu bytes needed)", need);
+        if (workspace_bytes < need)
+            return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+        if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
+    }
     const void* src[3] = {q, k, v};
     const int64_t* strd[3] = {q_strides, k_strides, v_strides};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -324,7 +351,7 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     char* w = static_cast<char*>(workspace);
     char* wt[3] = {w, w + one_q, w + one_q + one_kv};   // the workspace holds the converted tensors back to back
     if (native_qk) wt[2] = w;
-    for (int t = native_qk ? 2 : 0; t < 3; ++t) {
+    for (int t = native_v ? 3 : (native_qk ? 2 : 0); t < 3; ++t) {
         const int per_slice = rows[t] * (D / 16);
         const int bx = std::max(1, std::min((per_slice + 255) / 256, 64));
         const long long blocks = (long long)bx * B * heads[t];
@@ -340,10 +367,9 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
         return fa_fwd_ex(wt[0], wt[1], wt[2], o, lse, B, H, H_kv, S, S_k, D, nullptr, nullptr, nullptr, o_strides,
                          FA_DTYPE_BF16, causal, softmax_scale, descale, stream);
 
-    if (!o) return fail(FA_ERR_NULL_PTR, "null tensor pointer");
     fa::FwdParams p;
     memset(&p, 0, sizeof(p));
-    p.q = q; p.k = k; p.v = w; p.o = o; p.lse = lse;
+    p.q = q; p.k = k; p.v = native_v ? v : w; p.o = o; p.lse = lse;
     p.B = B; p.H = H; p.S = S; p.Sk = S_k; p.dv = D;
     p.G = H / H_kv;
     p.nqb = (S + fa::kBM - 1) / fa::kBM;
@@ -355,12 +381,15 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     p.bh = B * H;
     p.q_sb = st[0][0]; p.q_sh = st[0][1]; p.q_ss = st[0][2];
     p.k_sb = st[1][0]; p.k_sh = st[1][1]; p.k_ss = st[1][2];
-    p.v_ss = D; p.v_sh = (long long)S_k * D; p.v_sb = (long long)H_kv * S_k * D;
+    if (native_v) { p.v_sb = st[2][0]; p.v_sh = st[2][1]; p.v_ss = st[2][2]; }       // fp8 V in place: byte strides
+    else { p.v_ss = D; p.v_sh = (long long)S_k * D; p.v_sb = (long long)H_kv * S_k * D; }   // the bf16 copy, contiguous (element strides)
     if (!set_strides(o_strides, H, S, D, p.o_sb, p.o_sh, p.o_ss)) return fail(FA_ERR_BAD_STRIDE, "bad output strides");
     if ((p.o_sb * 2) % 16 || (p.o_sh * 2) % 16 || (p.o_ss * 2) % 16 || reinterpret_cast<uintptr_t>(o) % 16)
         return fail(FA_ERR_BAD_STRIDE, "output rows must be 16-byte aligned");
-    const long long max_ss = std::max(std::max(p.q_ss, p.k_ss), std::max(2 * p.v_ss, 2 * p.o_ss));
-    if (((long long)std::max(S, S_k) + 4 * fa::kBN) * max_ss >= (1ll << 31))
+    // 32-bit buffer offsets inside one (batch, head) slice, with room for the prefetched tiles (byte strides; V, O 16-bit
+    // where they are not fp8)
+    const long long max_ss = std::max(std::max(p.q_ss, p.k_ss), std::max((native_v ? 1 : 2) * p.v_ss, 2 * p.o_ss));
+    if (((long long)std::max(S, S_k) + 4 * fa::kBN8) * max_ss >= (1ll << 31))
         return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d)", std::max(S, S_k));
     const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
     const float dq = descale ? descale[0] : 1.f, dkk = descale ? descale[1] : 1.f, dvv = descale ? descale[2] : 1.f;
@@ -369,7 +398,18 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     p.out_scale = dvv;
     const int grid = grid_for(B, H, S, causal != 0);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
+    if (native_v) return causal ? launch8<true>(p, grid, s) : launch8<false>(p, grid, s);
     return causal ? launch16_qk8<true>(p, grid, s) : launch16_qk8<false>(p, grid, s);
+}
+
+// 1 if the fp8 entry runs P V on fp8 MFMAs too (head_dim > 64), 0 if that product runs on bf16 MFMAs
+int fa_fp8_pv_native(void)
+{
+#if defined(FA_FP8_CONVERT_ALL) || defined(FA_MFMA32) || FA_QB != 1 || defined(FA_FP8_PV_BF16)
+    return 0;
+#else
+    return 1;
+#endif
 }
 
 int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,

@@ -1,0 +1,531 @@
+// FlashAttention forward for gfx950 -- fp8 (OCP e4m3) Q, K, V with BOTH matrix products on MX-scaled fp8 MFMAs
+// (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: twice the 16-bit rate), head_dim 65..128, bf16 output.
+//
+// BASELINE.json config 5 ("fp8 Q/K/V (CDNA4 fp8 MFMA)").  Same workgroup shape, grid mapping, LDS-DMA ring, fixed softmax
+// reference + exact fallback and epilogue as fa_fwd_kernel16.hpp (read that header and fa_fwd_kernel.hpp first).  What changes:
+//
+//   * a K/V tile is 128 keys x 128 bytes (fp8): the K = 128 instruction sums over the whole head_dim in the score product
+//     and over 128 KEYS in the P V product, so a wave walks 128-key blocks, one workgroup barrier per block;
+//   * S^T (16 keys x 16 queries) = K . Q^T, ONE MFMA per tile.  The instruction's k index is only summed over, so any
+//     (lane group, byte) -> k map serves as long as both operands use the same one.  Here: lane (i, g) holds bytes
+//     16 g .. 16 g + 15 and 64 + 16 g .. 64 + 16 g + 15 of its row (two ds_read_b128 of K, two 16-byte loads of Q);
+//   * O^T (16 head_dim x 16 queries) += V^T[16 x 128 keys] . P^T[128 keys x 16].  B = P^T: byte 4 kt + e of lane (i, g) is
+//     the S^T accumulator element e of key tile kt (key 16 kt + 4 g + e), converted to e4m3: again the accumulators in register
+//     order ARE the operand.  A = V^T: byte 4 kt + e of lane (i', g) must be V[key 16 kt + 4 g + e][16 dt + i']: four
+//     ds_read_b64_tr_b8 per head_dim tile, each gathering 8 key rows (key tiles 2 m and 2 m + 1) x 16 columns
+//     (tools/probes/ds_read_tr8_probe.cpp: lane 2 q + p of a 16-lane group supplies the address of row q, lane i receives
+//     column i of the 8 rows);
+//   * P in e4m3: P = exp2(score - reference) with the reference fixed from the row's first 16 keys (bias 0), so typical P lies
+//     in 2^-7 .. 2^3; a block sum >= 256 in any lane (some P may have passed e4m3's 448) sends the workgroup to the exact
+//     loop, which keeps a running maximum and P <= 128.  Row sums and the LSE come from the fp32 P (before rounding).
+//     The e4m3 rounding of P (3 mantissa bits) is the accuracy cost of this kernel: ~2.7 % relative Frobenius error
+//     against the 5 % bound BASELINE.md states for fp8 inputs.
+//   * software pipeline at key-tile granularity: region R of block n issues S(n) of key tile R, the softmax slice of key
+//     tile R - 1, and the two P V MFMAs of head_dim tile R - 1 of block n - 1 (region 0: tile 7 of block n - 2): the
+//     score accumulators live in two 8-register slots instead of a 64-register block.
+#pragma once
+#include "fa_fwd_kernel.hpp"
+
+namespace fa {
+
+constexpr int kBN8 = 128;                      // keys per tile (= per block) of the fp8 kernel
+constexpr float kPBias8 = 0.0f;                // log2 offset of the softmax reference (P of the reference score = 2^-bias)
+constexpr float kPLimit8 = 256.0f;             // a lane's block sum of P at or above this -> exact fallback
+
+// 16-byte-chunk swizzles of the 128-byte rows (two rows per 256-byte bank row)
+//  K, read by rows (ds_read_b128, chunks g and g + 4 of row i): chunk ^ ((row >> 1) & 7)
+//  V, read transposed (8-byte pieces of keys 4 g + e (+ 16) per 16-lane group): chunk ^ (((key >> 1) & 3) | (((key >> 4) & 1) << 2))
+__device__ __forceinline__ int k8_swz(int row, int ch) { return ch ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int v8_swz(int row, int ch) { return ch ^ (((row >> 1) & 3) | (((row >> 4) & 1) << 2)); }
+
+__device__ __forceinline__ f32x4 mfma8(i32x8 a, i32x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+__device__ __forceinline__ i32x2 lds_read_tr8_b64(unsigned addr) {
+    return __builtin_amdgcn_ds_read_tr8_b64_v2i32(reinterpret_cast<__attribute__((address_space(3))) i32x2*>(addr));
+}
+// two fp32 -> two e4m3 bytes in the low (hi = false) or high half of `old`
+__device__ __forceinline__ int pack_fp8(float a, float b, int old, bool hi) {
+    return hi ? __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, false);
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
+{
+    constexpr int NWAVES = 8;
+    constexpr int ROWB = 128;                  // bytes per K / V row in LDS
+    constexpr int TILE = kBN8 * ROWB;          // 16 KiB per K (or V) tile
+    constexpr int PIECE = 1024;
+    constexpr int CPT = TILE / PIECE / NWAVES; // DMA pieces per wave and tile (2)
+    constexpr int DT = 8;                      // 16-wide head_dim tiles
+    constexpr int VBASE = kStages * TILE;
+    typedef TypeBF16 T;                        // output type
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // K ring [kStages][TILE], then V ring
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const bool paired = CAUSAL && !p.unpaired;
+    const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
+    int head, tq;
+    if (!wg_decode(blockIdx.x, p.bh, wg_per_head, p.hsplit, head, tq)) return;
+    const int b = head / p.H;
+    const int h = head - b * p.H;
+    const int S = p.S, Sk = p.Sk;
+    const int coff = CAUSAL ? Sk - S : 0;
+    const int n_pass = (paired && (p.nqb - 1 - tq != tq)) ? 2 : 1;
+
+    using elem_t = unsigned short;
+    const int hk = h / p.G;
+    const char* qh = reinterpret_cast<const char*>(p.q) + b * p.q_sb + h * p.q_sh;          // fp8: element strides = byte strides
+    const char* kh = reinterpret_cast<const char*>(p.k) + b * p.k_sb + hk * p.k_sh;
+    const char* vh = reinterpret_cast<const char*>(p.v) + b * p.v_sb + hk * p.v_sh;
+    elem_t* oh = reinterpret_cast<elem_t*>(p.o) + b * p.o_sb + h * p.o_sh;
+    const unsigned q_bytes = (unsigned)((long long)(S - 1) * p.q_ss + p.dv);
+    const unsigned k_bytes = (unsigned)((long long)(Sk - 1) * p.k_ss + p.dv);
+    const unsigned v_bytes = (unsigned)((long long)(Sk - 1) * p.v_ss + p.dv);
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(qh), 0, q_bytes, 0x00020000);
+    const u32x4 rk_w = make_rsrc(kh, k_bytes);
+    const u32x4 rv_w = make_rsrc(vh, v_bytes);
+
+    i32x8 qf[2];               // Q fragments [query tile]: 32 bytes per lane (chunks g and g + 4 of the row)
+
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int qb = CAUSAL ? ((pass == 0) ? p.nqb - 1 - tq : tq) : tq;
+    const int lane = lane_here();
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+    const int rowblk_of_wave = CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave;
+    const int q0w = qb * kBM + rowblk_of_wave * 32;
+
+    const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * kBM + kBM + coff)) : Sk;
+    const int nt = (kv_end_wg + kBN8 - 1) / kBN8;                     // 128-key tiles the workgroup stages
+    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
+    const int my_nt = (kv_end_w + kBN8 - 1) / kBN8;                   // tiles this wave computes on
+
+    auto load_q = [&](int qblk, int lane_q) {
+        const int li_ = lane_q & 15, lg_ = lane_q >> 4;
+        const int row0 = qblk * kBM + rowblk_of_wave * 32;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qrow = row0 + 16 * qt + li_;
+            const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss) : 0x80000000u;   // rows past the end read as zero
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int ch = lg_ + 4 * hh;
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rq, (ch * 16 < p.dv) ? qoff + ch * 16 : 0x80000000u, 0, 0);
+                qf[qt][4 * hh] = (int)w[0]; qf[qt][4 * hh + 1] = (int)w[1]; qf[qt][4 * hh + 2] = (int)w[2]; qf[qt][4 * hh + 3] = (int)w[3];
+            }
+        }
+    };
+    if (pass == 0) load_q(qb, lane);
+
+    // ---- K/V staging by LDS-DMA (1-KiB pieces = 8 rows; swizzle on the per-lane source address)
+    unsigned g_koff[CPT], g_voff[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int byte = (wave * CPT + i) * PIECE + lane * 16;
+        const int row = byte / ROWB, chp = (byte % ROWB) / 16;
+        const int ck = k8_swz(row, chp), cv = v8_swz(row, chp);
+        g_koff[i] = (ck * 16 < p.dv) ? (unsigned)(row * p.k_ss + ck * 16) : 0x80000000u;
+        g_voff[i] = (cv * 16 < p.dv) ? (unsigned)(row * p.v_ss + cv * 16) : 0x80000000u;
+    }
+    const unsigned k_tile_stride = (unsigned)(kBN8 * p.k_ss);
+    const unsigned v_tile_stride = (unsigned)(kBN8 * p.v_ss);
+    const unsigned piece_base = lds_base + wave * CPT * PIECE;       // wave-uniform
+    auto dma_k = [&](int j, unsigned stage_off) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            dma16(rk_w, __builtin_amdgcn_readfirstlane(piece_base + stage_off + i * PIECE), (unsigned)j * k_tile_stride + g_koff[i]);
+    };
+    auto dma_v = [&](int j, unsigned stage_off) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+            dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + stage_off + i * PIECE), (unsigned)j * v_tile_stride + g_voff[i]);
+    };
+
+    // ---- LDS read addresses; they carry the ring stage of the tile being read (K: tile j, V: tile j - 1)
+    unsigned ka[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) ka[hh] = lds_base + li * ROWB + (k8_swz(li, lg + 4 * hh) << 4);
+    unsigned va[DT];
+    {
+        const int qq = li >> 1, pp = li & 1;
+        const int key_in = 16 * (qq >> 2) + 4 * lg + (qq & 3);        // + 32 m: swizzle-neutral
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) va[dt] = lds_base + VBASE + key_in * ROWB + (v8_swz(key_in, dt) << 4) + 8 * pp;
+    }
+#if defined(FA8_DBUF)
+    constexpr int NFB = 2;     // fragment double buffers (by region parity)
+#else
+    constexpr int NFB = 1;     // one K and one V^T fragment: a region re-reads it right behind the MFMAs that consumed it
+#endif
+    i32x8 kf[NFB], vf[NFB];
+    auto read_k = [&] __device__ (auto kt_c, auto buf_c) {
+        constexpr int kt = decltype(kt_c)::value, buf = decltype(buf_c)::value;
+        const u32x4 w0 = lds_read_b128(ka[0] + kt * 16 * ROWB), w1 = lds_read_b128(ka[1] + kt * 16 * ROWB);
+        kf[buf % NFB] = i32x8{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+    };
+    auto read_v = [&] __device__ (auto dt_c, auto buf_c) {
+        constexpr int dt = decltype(dt_c)::value, buf = decltype(buf_c)::value;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const i32x2 w = lds_read_tr8_b64(va[dt] + m * 32 * ROWB);
+            vf[buf % NFB][2 * m] = w[0];
+            vf[buf % NFB][2 * m + 1] = w[1];
+        }
+    };
+
+    f32x4 o_acc[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // row sums of the ROUNDED P (what the P V product really weighs V with), from the matrix pipe: one more "head_dim tile"
+    // whose V^T fragment is all ones.  Every lane (i, g) then holds the full sum of query i in all four elements: no lane
+    // exchange, and O = sum(P~ V) / sum(P~) is a properly normalised average (V = 1 gives O = 1 exactly; a row with one
+    // dominant key returns that key's V).  The LSE uses the exact fp32 sums below.
+    f32x4 l_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const i32x8 ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};   // e4m3 1.0
+    float m_c[2] = {-INFINITY, -INFINITY};
+    float l_sum[2] = {0.f, 0.f};                       // this lane's share of the exact row sums (committed per block)
+    float lb_a[2] = {0.f, 0.f}, lb_b[2] = {0.f, 0.f};  // ... of the block in progress: two add chains per query tile
+    float peak = 0.f;                                  // largest block sum seen
+    const float c = p.scale_log2;
+
+    // mask: key (relative to the lane's first key 4 g of a tile) is dead iff it exceeds limq - (first key of the tile); the
+    // per-element compares then run against immediates (no per-(tile, element) index vectors kept alive across the loops)
+    int limq[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qrow = q0w + 16 * qt + li;
+        limq[qt] = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - 4 * lg;
+    }
+
+    f32x4 s_acc[2][2];         // S^T tiles [slot = key tile parity][query tile]
+    i32x8 pf[2][2];            // P^T fragments [block parity][query tile], dword kt
+
+    auto sm_slice = [&] __device__ (auto mask_c, auto par_c, auto kt_c, int key0) {
+        constexpr bool MASK = decltype(mask_c)::value;
+        constexpr int par = decltype(par_c)::value, kt = decltype(kt_c)::value;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x4 sv = s_acc[kt & 1][qt];
+            if constexpr (MASK) {
+                const int lim = limq[qt] - key0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (16 * kt + e > lim) sv[e] = -INFINITY;
+            }
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[0], c, -m_c[qt]));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[1], c, -m_c[qt]));
+            const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[2], c, -m_c[qt]));
+            const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[3], c, -m_c[qt]));
+            lb_a[qt] += p0; lb_b[qt] += p1; lb_a[qt] += p2; lb_b[qt] += p3;
+            pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, 0, false), true);
+            if constexpr (kt == 7) {           // last slice of the block: commit its row-sum share
+                const float t = lb_a[qt] + lb_b[qt];
+                l_sum[qt] += t;
+                peak = fmaxf(peak, t);
+                lb_a[qt] = lb_b[qt] = 0.f;
+            }
+        }
+    };
+    // the first key tile of a row's first block fixes its softmax reference
+    auto sm_set_reference = [&] __device__ (auto mask_c, int key0) {
+        constexpr bool MASK = decltype(mask_c)::value;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+            const int lim = limq[qt] - key0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = s_acc[0][qt][e];
+                if constexpr (MASK) {
+                    if (e > lim) v = -INFINITY;
+                }
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_c[qt] = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, kPBias8);
+        }
+    };
+
+    // ---- ring protocol (as fa_fwd_kernel.hpp, with 128-key tiles): iteration j reads K(j) (and K(j+1)'s first fragment in its
+    // last region) and V(j-1); barrier(j) sits in the middle of the iteration, behind it K(j+3) and V(j+2) are issued.
+    auto issue_prologue = [&]() {
+        dma_k(0, 0);
+        dma_v(0, 0);
+        dma_k(1, TILE);
+        dma_k(2, 2 * TILE);
+        dma_v(1, TILE);
+    };
+    if (pass == 0) issue_prologue();
+    dma_wait<3 * CPT>();        // this wave's pieces of K(0), V(0) have landed ...
+    __syncthreads();            // ... and every wave's are visible
+
+    int stage_k = 0;                               // ring stage of tile j
+    auto sync_and_stage = [&](int j) {
+        dma_wait<2 * CPT>();                       // everything but the previous iteration's DMA has landed ...
+        __syncthreads();                           // ... and is published; the stages refilled below are no longer read
+        dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
+        dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+    };
+    auto advance_k = [&]() {                       // K(j) -> K(j+1)
+        const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
+        ka[0] += d; ka[1] += d;
+    };
+    int stage_v = 0;                               // ring stage the V^T read addresses point at (block 1 reads V(0))
+    auto advance_v = [&]() {                       // V(t) -> V(t+1): called in front of every block j >= 2 (block j reads V(j-1))
+        const int d = (stage_v == kStages - 1) ? -(kStages - 1) * TILE : TILE;
+        stage_v = (stage_v + 1) & (kStages - 1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) va[dt] += d;
+    };
+
+    // One block n (= iteration j = n), eight regions R.  PAR = the P^T buffer the block's own slices fill:
+    //   DO_S : S(n), key tile R                       SL : softmax slice of key tile R - 1 (R >= 1) of block n -> pf[PAR]
+    //   SL0  : region 0, slice of key tile 7 of block n - 1 -> pf[PAR ^ 1]
+    //   PV   : region 0: P V of head_dim tile 7 of block n - 2 (P in pf[PAR]); regions 1..7: tile R - 1 of block n - 1 (pf[PAR ^ 1])
+    //   LDS  : region R reads the K fragment of key tile R + 1 (region 7: tile 0 of block n + 1) and the V^T fragment of
+    //          head_dim tile R of block n - 1 (consumed in region R + 1 / region 0 of the next block)
+    //   sync : barrier(n) and the staging DMAs behind region 3 (every wave runs it for every tile of the workgroup)
+    // Only two forms run more than a few times per pass: the unmasked pair (PAR 0 then PAR 1) of the steady state.  Every
+    // other block (the second, an odd one out, diagonal / ragged blocks, the drain) runs the masked PAR = 0 form followed
+    // by a swap of the two P^T buffers, so that block parity never has to be known at run time.  Blocks that have no
+    // predecessor to finish multiply zeroed fragments (pf, vf start at zero), which keeps the forms few.
+    auto block8 = [&] __device__ (auto par_c, auto do_s_c, auto sl0_c, auto sl_c, auto pv_c, auto mask_c, auto first_c, bool do_sync, int n) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool DO_S = decltype(do_s_c)::value, SL0 = decltype(sl0_c)::value, SL = decltype(sl_c)::value;
+        constexpr bool PV = decltype(pv_c)::value, FIRST = decltype(first_c)::value;
+        const int key0 = n * kBN8;
+        auto region = [&] __device__ (auto r_c) {
+            constexpr int R = decltype(r_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PV) {
+                constexpr int dt = (R == 0) ? 7 : R - 1;
+                constexpr int par = (R == 0) ? PAR : (PAR ^ 1);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = mfma8(vf[(R & 1) % NFB], pf[par][qt], o_acc[dt][qt]);
+                if constexpr (R == 4) {        // the ones tile of block n - 1
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) l_acc[qt] = mfma8(ones8, pf[PAR ^ 1][qt], l_acc[qt]);
+                }
+            }
+            if constexpr (DO_S) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s_acc[R & 1][qt] = mfma8(kf[(R & 1) % NFB], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                if constexpr (R == 7) advance_k();
+                read_k(IC<(R + 1) & 7>{}, IC<(R + 1) & 1>{});
+            }
+            if constexpr (PV) read_v(IC<R>{}, IC<(R + 1) & 1>{});
+            if constexpr (R == 0) {
+                if constexpr (SL0) sm_slice(mask_c, IC<PAR ^ 1>{}, IC<7>{}, key0 - kBN8);
+            } else if constexpr (SL) {
+                if constexpr (FIRST && R == 1) sm_set_reference(mask_c, key0);
+                sm_slice(mask_c, IC<PAR>{}, IC<R - 1>{}, key0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (R == 3) {
+                if (do_sync) sync_and_stage(n);
+            }
+        };
+        region(IC<0>{}); region(IC<1>{}); region(IC<2>{}); region(IC<3>{});
+        region(IC<4>{}); region(IC<5>{}); region(IC<6>{}); region(IC<7>{});
+    };
+    auto swap_pf = [&]() {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) { const i32x8 t = pf[0][qt]; pf[0][qt] = pf[1][qt]; pf[1][qt] = t; }
+    };
+    typedef std::true_type Y;
+    typedef std::false_type N_;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) pf[0][qt] = pf[1][qt] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NFB; ++i) vf[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int NT = my_nt;
+    // first block whose softmax needs the mask (the wave's diagonal block, or the ragged last one)
+    const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 7) : 0x7fffffff, Sk >> 7);
+    int j = 0;
+    if (NT > 0) {
+        read_k(IC<0>{}, IC<0>{});
+        // block 0 (pipeline fill): scores and slices only; its first key tile fixes the reference
+        block8(IC<0>{}, Y{}, N_{}, Y{}, N_{}, Y{}, Y{}, true, 0);
+        swap_pf();
+        stage_k = (stage_k + 1) & (kStages - 1);
+        j = 1;                                         // (block 1 reads V(0): the first advance_v follows block 1)
+        const int ja = min(mb, NT);
+        for (; j + 1 < ja; j += 2) {                   // steady state: pairs of unmasked blocks
+            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, true, j);
+            stage_k = (stage_k + 1) & (kStages - 1);
+            advance_v();
+            block8(IC<1>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, true, j + 1);
+            stage_k = (stage_k + 1) & (kStages - 1);
+            advance_v();
+        }
+        for (; j < NT; ++j) {                          // an odd block out, diagonal / ragged blocks: masked form + buffer swap
+            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, Y{}, N_{}, true, j);
+            swap_pf();
+            stage_k = (stage_k + 1) & (kStages - 1);
+            advance_v();
+        }
+        // drain, "block" NT: the last slice, P V of block NT - 1 (tiles 0..6) and of block NT - 2 (tile 7) ...
+        const bool sync_d = j < nt;
+        block8(IC<0>{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, sync_d, j);
+        if (sync_d) stage_k = (stage_k + 1) & (kStages - 1);
+        ++j;
+        // ... and tile 7 of block NT - 1 (its V^T fragment was read in region 7 above)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o_acc[7][qt] = mfma8(vf[0], pf[1][qt], o_acc[7][qt]);
+    }
+    for (; j < nt; ++j) {                              // remaining tiles of the workgroup: staging duty only
+        sync_and_stage(j);
+        stage_k = (stage_k + 1) & (kStages - 1);
+    }
+
+    // ---- exact fallback (rare): per-block online softmax with running maximum and rescale, P = exp2(score - max + 7) <= 128
+    float l_part[2] = {l_sum[0], l_sum[1]};
+    dma_wait<0>();
+#if defined(FA8_NOFALLBACK)
+    if (false) {
+#else
+    if (wg_any(!(peak < kPLimit8), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
+#endif
+        constexpr int KO = 0, VO = VBASE;
+        const int lane_f = lane_here();
+        const int li = lane_f & 15, lg = lane_f >> 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_r[2] = {-INFINITY, -INFINITY};
+        l_part[0] = l_part[1] = 0.f;
+        l_acc[0] = l_acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned ka2[2], va2[DT];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) ka2[hh] = lds_base + KO + li * ROWB + (k8_swz(li, lg + 4 * hh) << 4);
+        {
+            const int qq = li >> 1, pp = li & 1;
+            const int key_in = 16 * (qq >> 2) + 4 * lg + (qq & 3);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) va2[dt] = lds_base + VO + key_in * ROWB + (v8_swz(key_in, dt) << 4) + 8 * pp;
+        }
+        auto dma2 = [&](int jj) {
+            const unsigned st = (jj & 1) * TILE;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                dma16(rk_w, __builtin_amdgcn_readfirstlane(piece_base + KO + st + i * PIECE), (unsigned)jj * k_tile_stride + g_koff[i]);
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+                dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VO + st + i * PIECE), (unsigned)jj * v_tile_stride + g_voff[i]);
+        };
+        dma2(0);
+        for (int jj = 0; jj < nt; ++jj) {
+            dma_wait<0>();
+            __syncthreads();                   // tile jj landed and is visible; tile jj-1's stage is free
+            dma2(jj + 1);
+            if (jj < my_nt) {
+                const unsigned st = (jj & 1) * TILE;
+                const int key0 = jj * kBN8;
+                f32x4 sx[8][2];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt) {
+                    const u32x4 w0 = lds_read_b128(ka2[0] + st + kt * 16 * ROWB), w1 = lds_read_b128(ka2[1] + st + kt * 16 * ROWB);
+                    const i32x8 kx = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) sx[kt][qt] = mfma8(kx, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+                i32x8 px[2];
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int qrow = q0w + 16 * qt + li;
+                    const int lim = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - 4 * lg - key0;
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (16 * kt + e > lim) sx[kt][qt][e] = -INFINITY;
+                            mx = fmaxf(mx, sx[kt][qt][e]);
+                        }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float m_new = fmaxf(m_r[qt], mx * c);
+                    const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_r[qt] - m_new);
+                    l_part[qt] *= alpha;
+                    l_acc[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) o_acc[dt][qt] *= alpha;
+                    m_r[qt] = m_new;
+                    const float m_sub = (m_new == -INFINITY) ? 0.f : m_new - 7.0f;     // P <= 2^7 (row fully masked so far: anything)
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kt][qt][0], c, -m_sub));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kt][qt][1], c, -m_sub));
+                        const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kt][qt][2], c, -m_sub));
+                        const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[kt][qt][3], c, -m_sub));
+                        l_part[qt] += (p0 + p1) + (p2 + p3);
+                        px[qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, 0, false), true);
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    i32x8 vx;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const i32x2 w = lds_read_tr8_b64(va2[dt] + st + m * 32 * ROWB);
+                        vx[2 * m] = w[0];
+                        vx[2 * m + 1] = w[1];
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = mfma8(vx, px[qt], o_acc[dt][qt]);
+                }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) l_acc[qt] = mfma8(ones8, px[qt], l_acc[qt]);
+            }
+        }
+        // sums and outputs carry the factor 2^7: the reference the epilogue sees is max - 7
+        m_c[0] = (m_r[0] == -INFINITY) ? 0.f : m_r[0] - 7.0f;
+        m_c[1] = (m_r[1] == -INFINITY) ? 0.f : m_r[1] - 7.0f;
+        dma_wait<0>();
+        __syncthreads();
+    }
+
+    if (pass + 1 < n_pass) {
+        issue_prologue();
+        load_q(tq, lane_here());
+    }
+
+    // ---- epilogue (as fa_fwd_kernel16.hpp)
+    const int lane_e = lane_here();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int li = lane_e & 15, lg = lane_e >> 4;
+        float l = l_part[qt];                                       // exact row sum (LSE)
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float lq = l_acc[qt][0];                              // sum of the rounded P of query li (normalisation)
+        const float inv = (lq > 0.f) ? p.out_scale / lq : 0.f;      // flash_attn_cutlass.cu:446-452 guard
+        const int qrow = q0w + 16 * qt + li;
+        if (p.lse != nullptr && lg == 0 && qrow < S)
+            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+        elem_t* orow = oh + (long long)qrow * p.o_ss;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt += 2) {
+            const f32x4 oa = o_acc[dt][qt], ob = o_acc[dt + 1][qt];
+            unsigned a0 = T::pack2(oa[0] * inv, oa[1] * inv), a1 = T::pack2(oa[2] * inv, oa[3] * inv);
+            unsigned b0 = T::pack2(ob[0] * inv, ob[1] * inv), b1 = T::pack2(ob[2] * inv, ob[3] * inv);
+            auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+            const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+            if (qrow < S && col < p.dv) *reinterpret_cast<u32x4*>(orow + col) = outv;
+        }
+    }
+  }  // pass
+}
+
+}  // namespace fa

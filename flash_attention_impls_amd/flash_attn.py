@@ -84,6 +84,8 @@ def _declare(lib):
                            c.POINTER(c.c_float), c.c_void_p]
     lib.fa_fp8_workspace_bytes.restype = c.c_size_t
     lib.fa_fp8_workspace_bytes.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int]
+    lib.fa_fp8_pv_native.restype = c.c_int
+    lib.fa_fp8_pv_native.argtypes = []
     lib.fa_fwd_fp8.restype = c.c_int
     lib.fa_fwd_fp8.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                c.c_int, c.c_int, c.c_int, c.c_int,

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 120          /* 0.1.2: + extended entry points (H_kv, S_k) (0.1.1: + backward) */
+#define FA_VERSION 130          /* 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -90,16 +90,20 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
            const float* descale, void* stream);
 
 /*
- * fp8 (OCP e4m3fn) Q/K/V, bf16 O.  head_dim > 64: Q and K are consumed as fp8 by the score MFMAs
- * (v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales: the whole head_dim per instruction); V is converted (exactly) to bf16 into the caller-provided device workspace by a HIP
- * pre-pass, because P V runs on bf16 MFMAs with P from the fp32 softmax.  head_dim <= 64: all three tensors are
- * converted and the bf16 kernel runs.  The q,k dequantisation scales are folded into the softmax scale, the v scale
- * into the output.  No reference counterpart (the reference is fp16 only); BASELINE.json config 5.
+ * fp8 (OCP e4m3fn) Q/K/V, bf16 O.  head_dim > 64: all three tensors are consumed as fp8 by the matrix cores -- both
+ * Q K^T and P V run on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (the whole head_dim, resp. 128 keys, per
+ * instruction; P is rounded to e4m3 after the fp32 softmax, the row sums and the LSE use the unrounded P) -- and no
+ * workspace is needed.  head_dim <= 64: all three tensors are converted (exactly) to bf16 into the caller-provided
+ * workspace by a HIP pre-pass and the bf16 kernel runs.  The q, k dequantisation scales are folded into the softmax
+ * scale, the v scale into the output.  No reference counterpart (the reference is fp16 only); BASELINE.json
+ * config 5.  Stated accuracy for fp8 inputs: relative Frobenius error <= 5 %.
  *   strides are in elements (= bytes) with unit head_dim stride; rows and bases 16-byte aligned.
- *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes (one bf16 tensor for head_dim > 64,
- *              three otherwise), 16-byte aligned.
+ *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes, 16-byte aligned (0 bytes for
+ *              head_dim > 64: the pointer may then be NULL; three bf16 tensors otherwise).
+ * fa_fp8_pv_native(): 1 if P V of the fp8 entry runs on fp8 MFMAs (this build's default), 0 if on bf16 MFMAs.
  */
 size_t fa_fp8_workspace_bytes(int B, int H, int S, int D);
+int fa_fp8_pv_native(void);
 int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
                int B, int H, int S, int D,
                const int64_t* q_strides, const int64_t* k_strides,

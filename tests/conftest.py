@@ -16,6 +16,9 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # stated floating-point tolerances (BASELINE.md §4 / SURVEY.md §4): |o - ref| <= tol * max(1, |ref|)
 TOL = {"bf16": 1.6e-2, "fp16": 2e-3, "fp32": 2e-3}   # fp32 inputs are computed in fp16 (FA2-triton.py:241-244)
 FP8_REL_FRO = 5e-2
+# fp8 inputs, head_dim > 64: P is rounded to e4m3 for the P V product (3 mantissa bits: every weight is off by at most 2^-4
+# relative, a weighted average of V by at most 2^-4 * max|V|); element-wise bound |o - ref| <= FP8_TOL * max(1, max|ref|)
+FP8_TOL = 7e-2
 
 
 def pytest_configure(config):

@@ -33,13 +33,13 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             "fa_fwd_launch_info", "fa_fwd_fp8", "fa_fp8_workspace_bytes"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
-    assert lib.fa_version() == 120
+    assert lib.fa_version() == 130
     assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
 
 
 def test_supported_matrix():
     lib = fa.load_library()
-    assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 1 * 8 * 32 * 4096 * 128 * 2      # only V is converted
+    assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 0 and lib.fa_fp8_pv_native() == 1   # head_dim > 64: all three tensors feed fp8 MFMAs
     assert lib.fa_fp8_workspace_bytes(4, 8, 1024, 64) == 3 * 4 * 8 * 1024 * 64 * 2
     for dt in (0, 1, 2):
         # every head_dim the reference accepts: D % 16 == 0, D <= 128 (FA2-triton.py:178; dispatcher 32/64/128)
@@ -300,4 +300,4 @@ def test_concurrent_builds_compile_once_and_staleness_is_by_content(tmp_path):
     assert all(p.returncode == 0 for p in procs), errs
     assert log.read_text().count("call") == 1                    # one compile for four processes
     assert not _build.is_stale()
-    assert fa.load_library(_build.LIB_PATH).fa_version() == 120
+    assert fa.load_library(_build.LIB_PATH).fa_version() == 130

@@ -24,7 +24,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 def _lib_loaded_from_tree():
     lib = fa.load_library()
-    assert lib.fa_version() == 120
+    assert lib.fa_version() == 130
     return lib
 
 
@@ -71,10 +71,10 @@ def test_golden_vectors(name):
 
 @pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("fp8")])
 def test_golden_vectors_fp8(name):
-    """fp8-e4m3fn Q/K/V with per-tensor scales (BASELINE config 5 dtype): HIP conversion pre-pass + bf16 kernel.
-    Stated tolerance: relative Frobenius error <= 5 %; the conversion is exact, so the bf16
-    element-wise bound holds as well."""
-    from conftest import FP8_REL_FRO
+    """fp8-e4m3fn Q/K/V with per-tensor scales (BASELINE config 5 dtype), both products on fp8 MFMAs.
+    Stated tolerance: relative Frobenius error <= 5 %, element-wise FP8_TOL (P rounded to e4m3); the LSE
+    comes from the unrounded P and keeps the 1e-3 bound."""
+    from conftest import FP8_REL_FRO, FP8_TOL
     d = load_golden(name)
     q, k, v = [golden_torch(d, n, "cuda") for n in "qkv"]
     assert q.dtype == torch.float8_e4m3fn
@@ -84,7 +84,7 @@ def test_golden_vectors_fp8(name):
     ref = d["o"].astype(np.float64)
     of = o.float().cpu().numpy().astype(np.float64)
     assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
-    assert_close(o, ref, TOL["bf16"], name)
+    assert_close(o, ref, FP8_TOL, name)
     lse_ref = d["lse"].astype(np.float64)
     assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
 
@@ -101,11 +101,24 @@ def test_fp8_strided_and_raw_capi():
     o = fa.flash_attn(q8, k8, v8, True, descale=tuple(sc))
     qd, kd, vd = [t.float().cpu() * s_ for t, s_ in zip((q8, k8, v8), sc)]
     ref, _ = orc.naive_attention_f64(qd.numpy(), kd.numpy(), vd.numpy(), causal=True)
-    assert_close(o, ref, TOL["bf16"], "fp8 strided")
-    # too-small workspace and plain fa_fwd with the fp8 code are rejected before any launch
-    ws = torch.empty(16, dtype=torch.uint8, device="cuda")
+    from conftest import FP8_REL_FRO, FP8_TOL
+    assert_close(o, ref, FP8_TOL, "fp8 strided")
+    assert np.linalg.norm(o.float().cpu().numpy() - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    # head_dim 128 needs no workspace (all three tensors feed fp8 MFMAs): a raw call with a NULL workspace, own strides
+    assert lib.fa_fp8_workspace_bytes(B, H, S, D) == 0 and lib.fa_fp8_pv_native() == 1
     oc = torch.empty(B, H, S, D, dtype=torch.bfloat16, device="cuda")
+    dsc = (ctypes.c_float * 3)(*sc)
+    st = [(ctypes.c_int64 * 3)(*t.stride()[:3]) for t in (q8, k8, v8)]
     rc = lib.fa_fwd_fp8(q8.data_ptr(), k8.data_ptr(), v8.data_ptr(), oc.data_ptr(), None, B, H, S, D,
+                        st[0], st[1], st[2], None, 1, ctypes.c_float(0.0), dsc, None, 0, None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(oc, o)
+    # head_dim 64 converts to bf16 first: a too-small workspace is rejected before any launch; so is plain fa_fwd with fp8
+    q64 = torch.zeros(B, H, S, 64, device="cuda").to(torch.float8_e4m3fn)
+    o64 = torch.empty(B, H, S, 64, dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(16, dtype=torch.uint8, device="cuda")
+    assert lib.fa_fp8_workspace_bytes(B, H, S, 64) == 3 * B * H * S * 64 * 2
+    rc = lib.fa_fwd_fp8(q64.data_ptr(), q64.data_ptr(), q64.data_ptr(), o64.data_ptr(), None, B, H, S, 64,
                         None, None, None, None, 1, ctypes.c_float(0.0), None, ws.data_ptr(), 16, None)
     assert rc == -3 and b"workspace" in lib.fa_last_error()
     rc = lib.fa_fwd(q8.data_ptr(), k8.data_ptr(), v8.data_ptr(), oc.data_ptr(), None, B, H, S, D,
@@ -496,10 +509,12 @@ def test_fp8_small_head_dim():
     assert rel <= 5e-2, rel
 
 
-def test_fp8_native_qk_matches_convert_all_build(tmp_path):
-    """head_dim 128 fp8: the default path feeds Q and K to fp8 MFMAs; -DFA_FP8_CONVERT_ALL converts all three tensors to
-    bf16 first (the products are the same exact numbers either way): both within the fp8 tolerance of the oracle and
-    within bf16 rounding of each other."""
+@pytest.mark.parametrize("flag,close", [("-DFA_FP8_CONVERT_ALL", None), ("-DFA_FP8_PV_BF16", None)])
+def test_fp8_native_matches_converting_builds(tmp_path, flag, close):
+    """head_dim 128 fp8: the default path feeds all three tensors to fp8 MFMAs (P rounded to e4m3); -DFA_FP8_PV_BF16
+    (round 1: Q, K native, V converted, P V on bf16 MFMAs) and -DFA_FP8_CONVERT_ALL (all three converted to bf16 first) keep
+    P in bf16.  All within the fp8 tolerance of the oracle; the converting builds are the more accurate ones, and the
+    default stays within the P-rounding bound of them."""
     import importlib
     import shutil
     import subprocess
@@ -507,7 +522,7 @@ def test_fp8_native_qk_matches_convert_all_build(tmp_path):
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not available")
     so = str(tmp_path / "libfa_convert_all.so")
-    subprocess.run([_build.hipcc_path(), *_build.HIPCC_FLAGS, "-DFA_FP8_CONVERT_ALL", "-o", so, *_build.SOURCES],
+    subprocess.run([_build.hipcc_path(), *_build.HIPCC_FLAGS, flag, "-o", so, *_build.SOURCES],
                    check=True, capture_output=True)
     fa_mod = importlib.import_module("flash_attention_impls_amd.flash_attn")
     default = fa.load_library()
@@ -524,10 +539,9 @@ def test_fp8_native_qk_matches_convert_all_build(tmp_path):
             fa_mod._lib_handle = variant
             o1 = fa.flash_attn(q8, k8, v8, causal, descale=ds)
             ref, _ = orc.naive_attention_f64(*deq, causal=causal)
-            for o in (o0, o1):
-                rel = np.linalg.norm(o.float().cpu().numpy() - ref) / np.linalg.norm(ref)
-                assert rel <= 5e-2
-            assert (o0.float() - o1.float()).abs().max() <= 2 ** -6
+            rels = [np.linalg.norm(o.float().cpu().numpy() - ref) / np.linalg.norm(ref) for o in (o0, o1)]
+            assert rels[0] <= 5e-2 and rels[1] <= 1e-2, rels
+            assert (o0.float() - o1.float()).abs().max() <= 7e-2 * max(1.0, float(np.abs(ref).max()))
     finally:
         fa_mod._lib_handle = default
 

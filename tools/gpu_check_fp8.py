@@ -1,0 +1,67 @@
+"""Quick on-box sweep of the fp8 path (development aid; the parity tests proper are in tests/): shapes x masks against
+float64 attention of the dequantised inputs, printing relative Frobenius / max element / LSE errors."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+import flash_attention_impls_amd as fa
+
+torch.manual_seed(0)
+
+
+def ref64(q, k, v, ds, causal):
+    qd, kd, vd = [t.double() * s for t, s in zip((q, k, v), ds)]
+    G = q.shape[1] // k.shape[1]
+    kd, vd = kd.repeat_interleave(G, 1), vd.repeat_interleave(G, 1)
+    s = qd @ kd.transpose(-1, -2) / math.sqrt(q.shape[-1])
+    if causal:
+        Sq, Sk = s.shape[-2:]
+        i = torch.arange(Sq, device=s.device)[:, None]
+        jj = torch.arange(Sk, device=s.device)[None, :]
+        s = s.masked_fill(jj > i + (Sk - Sq), float("-inf"))
+    lse = torch.logsumexp(s, -1)
+    p = torch.exp(s - lse[..., None])
+    p = torch.nan_to_num(p)
+    return p @ vd, lse
+
+
+bad = 0
+for (B, H, Hkv, S, Sk, D, causal, mul) in [
+        (1, 2, 2, 128, 128, 128, False, 1), (1, 2, 2, 128, 128, 128, True, 1), (2, 3, 3, 333, 333, 128, True, 1),
+        (1, 2, 2, 1, 1, 128, True, 1), (1, 1, 1, 17, 17, 128, False, 1), (2, 4, 2, 777, 777, 128, False, 1),
+        (1, 2, 1, 1030, 1030, 128, True, 1), (1, 2, 2, 256, 1024, 128, True, 1), (1, 2, 2, 1024, 300, 128, True, 1),
+        (1, 2, 2, 512, 512, 96, False, 1), (1, 2, 2, 640, 640, 80, True, 1), (2, 8, 8, 2048, 2048, 128, False, 1),
+        (1, 4, 4, 2048, 2048, 128, True, 1), (1, 2, 2, 1024, 1024, 128, False, 6), (1, 2, 2, 1024, 1024, 128, True, 6)]:
+    f32 = [torch.randn(B, H, S, D, device="cuda") * mul, torch.randn(B, Hkv, Sk, D, device="cuda") * mul, torch.randn(B, Hkv, Sk, D, device="cuda")]
+    ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q, k, v = [(t / s).to(torch.float8_e4m3fn) for t, s in zip(f32, ds)]
+    o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    ref, lse_ref = ref64(q, k, v, ds, causal)
+    rel = float((o.double() - ref).norm() / ref.norm())
+    mx = float((o.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    fin = torch.isfinite(lse_ref)
+    le = float((lse.double() - lse_ref)[fin].abs().max()) if fin.any() else 0.0
+    inf_ok = bool(torch.equal(torch.isinf(lse), ~fin))
+    ok = rel <= 5e-2 and mx <= 7e-2 and le <= 1e-3 * max(1.0, float(lse_ref[fin].abs().max()) if fin.any() else 1.0) and inf_ok
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} B{B} H{H}/{Hkv} S{S}/{Sk} D{D} causal={int(causal)} mul={mul}: relF {rel:.4f} maxel {mx:.4f} lse {le:.2e}")
+# forced fallback: one key far above the first tile's scores
+B, H, S, D = 1, 2, 1024, 128
+f32 = [torch.randn(B, H, S, D, device="cuda") for _ in range(3)]
+f32[1][:, :, 700] = f32[0][:, :, 900] * 6.0            # key 700 aligned with query 900: a score spike far beyond 2^8 of the reference
+ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
+q, k, v = [(t / s).to(torch.float8_e4m3fn) for t, s in zip(f32, ds)]
+for causal in (False, True):
+    o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    ref, lse_ref = ref64(q, k, v, ds, causal)
+    rel = float((o.double() - ref).norm() / ref.norm())
+    le = float((lse.double() - lse_ref).abs().max())
+    ok = rel <= 5e-2 and le <= 1e-3 * float(lse_ref.abs().max())
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} spike causal={int(causal)}: relF {rel:.4f} lse {le:.2e} (max lse {float(lse_ref.abs().max()):.1f})")
+print("FAILURES:", bad)
+sys.exit(1 if bad else 0)
