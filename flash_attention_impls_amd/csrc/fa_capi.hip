@@ -81,16 +81,16 @@ int launch16_qk8(const fa::FwdParams& p, int grid, hipStream_t stream)
 }
 
 // head_dim > 64, fp8 Q, K and V, both products on MX-scaled fp8 MFMAs (fa_fwd_kernel8.hpp)
-template <bool CAUSAL>
+template <bool CAUSAL, bool WANT_LSE>
 int launch8(const fa::FwdParams& p, int grid, hipStream_t stream)
 {
     constexpr int lds = fa::kStages * 2 * fa::kBN8 * 128;
-    auto* kernel = &fa::fa_fwd_kernel8<CAUSAL>;
+    auto* kernel = &fa::fa_fwd_kernel8<CAUSAL, WANT_LSE>;
     struct Tag {};
     const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((fa::fa_fwd_kernel8<CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((fa::fa_fwd_kernel8<CAUSAL, WANT_LSE>), dim3(grid), dim3(512), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
@@ -398,7 +398,10 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     p.out_scale = dvv;
     const int grid = grid_for(B, H, S, causal != 0);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
-    if (native_v) return causal ? launch8<true>(p, grid, s) : launch8<false>(p, grid, s);
+    if (native_v) {
+        if (lse) return causal ? launch8<true, true>(p, grid, s) : launch8<false, true>(p, grid, s);
+        return causal ? launch8<true, false>(p, grid, s) : launch8<false, false>(p, grid, s);
+    }
     return causal ? launch16_qk8<true>(p, grid, s) : launch16_qk8<false>(p, grid, s);
 }
 

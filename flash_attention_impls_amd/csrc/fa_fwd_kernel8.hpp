@@ -16,8 +16,9 @@
 //     (tools/probes/ds_read_tr8_probe.cpp: lane 2 q + p of a 16-lane group supplies the address of row q, lane i receives
 //     column i of the 8 rows);
 //   * P in e4m3: P = exp2(score - reference) with the reference fixed from the row's first 16 keys (bias 0), so typical P lies
-//     in 2^-7 .. 2^3; a block sum >= 256 in any lane (some P may have passed e4m3's 448) sends the workgroup to the exact
-//     loop, which keeps a running maximum and P <= 128.  Row sums and the LSE come from the fp32 P (before rounding).
+//     in 2^-7 .. 2^3; a P beyond e4m3's range converts to NaN, which poisons the row's sum on the matrix pipe and sends the
+//     workgroup to the exact loop (running maximum, P <= 128).  O is normalised by the sum of the ROUNDED P (from a "ones"
+//     head_dim tile on the matrix pipe); the LSE comes from the exact fp32 sum, formed only when an LSE is asked for.
 //     The e4m3 rounding of P (3 mantissa bits) is the accuracy cost of this kernel: ~2.7 % relative Frobenius error
 //     against the 5 % bound BASELINE.md states for fp8 inputs.
 //   * software pipeline at key-tile granularity: region R of block n issues S(n) of key tile R, the softmax slice of key
@@ -30,7 +31,7 @@ namespace fa {
 
 constexpr int kBN8 = 128;                      // keys per tile (= per block) of the fp8 kernel
 constexpr float kPBias8 = 0.0f;                // log2 offset of the softmax reference (P of the reference score = 2^-bias)
-constexpr float kPLimit8 = 256.0f;             // a lane's block sum of P at or above this -> exact fallback
+constexpr float kPLimit8 = 1e30f;              // a rounded row sum not below this (i.e. NaN: some P left e4m3's range) -> exact fallback
 
 // 16-byte-chunk swizzles of the 128-byte rows (two rows per 256-byte bank row)
 //  K, read by rows (ds_read_b128, chunks g and g + 4 of row i): chunk ^ ((row >> 1) & 7)
@@ -50,7 +51,9 @@ __device__ __forceinline__ int pack_fp8(float a, float b, int old, bool hi) {
     return hi ? __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, true) : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, old, false);
 }
 
-template <bool CAUSAL>
+// WANT_LSE = false (the caller passed no LSE buffer): the exact fp32 row sums -- one v_add_f32 per score, a quarter of the
+// kernel's vector instructions -- are not formed at all; the output only needs the rounded sums, which the matrix pipe delivers.
+template <bool CAUSAL, bool WANT_LSE>
 __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 {
     constexpr int NWAVES = 8;
@@ -156,11 +159,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) va[dt] = lds_base + VBASE + key_in * ROWB + (v8_swz(key_in, dt) << 4) + 8 * pp;
     }
-#if defined(FA8_DBUF)
-    constexpr int NFB = 2;     // fragment double buffers (by region parity)
-#else
-    constexpr int NFB = 1;     // one K and one V^T fragment: a region re-reads it right behind the MFMAs that consumed it
-#endif
+    constexpr int NFB = 2;     // K and V^T fragment double buffers (by region parity): read two regions ahead of their MFMAs
     i32x8 kf[NFB], vf[NFB];
     auto read_k = [&] __device__ (auto kt_c, auto buf_c) {
         constexpr int kt = decltype(kt_c)::value, buf = decltype(buf_c)::value;
@@ -189,9 +188,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     f32x4 l_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const i32x8 ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};   // e4m3 1.0
     float m_c[2] = {-INFINITY, -INFINITY};
-    float l_sum[2] = {0.f, 0.f};                       // this lane's share of the exact row sums (committed per block)
-    float lb_a[2] = {0.f, 0.f}, lb_b[2] = {0.f, 0.f};  // ... of the block in progress: two add chains per query tile
-    float peak = 0.f;                                  // largest block sum seen
+    float l_a[2] = {0.f, 0.f}, l_b[2] = {0.f, 0.f};    // this lane's share of the exact row sums (LSE): two add chains per query tile
     const float c = p.scale_log2;
 
     // mask: key (relative to the lane's first key 4 g of a tile) is dead iff it exceeds limq - (first key of the tile); the
@@ -222,14 +219,10 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[1], c, -m_c[qt]));
             const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[2], c, -m_c[qt]));
             const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[3], c, -m_c[qt]));
-            lb_a[qt] += p0; lb_b[qt] += p1; lb_a[qt] += p2; lb_b[qt] += p3;
-            pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, 0, false), true);
-            if constexpr (kt == 7) {           // last slice of the block: commit its row-sum share
-                const float t = lb_a[qt] + lb_b[qt];
-                l_sum[qt] += t;
-                peak = fmaxf(peak, t);
-                lb_a[qt] = lb_b[qt] = 0.f;
-            }
+            if constexpr (WANT_LSE) { l_a[qt] += p0; l_b[qt] += p1; l_a[qt] += p2; l_b[qt] += p3; }
+            // (both halves of the word are overwritten: its old content serves as the conversions' pass-through operand,
+            // which saves the v_mov a fresh zero would cost.)  A P beyond e4m3's range (> 464) converts to NaN.
+            pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, pf[par][qt][kt], false), true);
         }
     };
     // the first key tile of a row's first block fixes its softmax reference
@@ -278,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         ka[0] += d; ka[1] += d;
     };
     int stage_v = 0;                               // ring stage the V^T read addresses point at (block 1 reads V(0))
-    auto advance_v = [&]() {                       // V(t) -> V(t+1): called in front of every block j >= 2 (block j reads V(j-1))
+    auto advance_v = [&]() {                       // V(t) -> V(t+1): in region 7 of every block but the first
         const int d = (stage_v == kStages - 1) ? -(kStages - 1) * TILE : TILE;
         stage_v = (stage_v + 1) & (kStages - 1);
 #pragma unroll
@@ -289,21 +282,30 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     //   DO_S : S(n), key tile R                       SL : softmax slice of key tile R - 1 (R >= 1) of block n -> pf[PAR]
     //   SL0  : region 0, slice of key tile 7 of block n - 1 -> pf[PAR ^ 1]
     //   PV   : region 0: P V of head_dim tile 7 of block n - 2 (P in pf[PAR]); regions 1..7: tile R - 1 of block n - 1 (pf[PAR ^ 1])
-    //   LDS  : region R reads the K fragment of key tile R + 1 (region 7: tile 0 of block n + 1) and the V^T fragment of
-    //          head_dim tile R of block n - 1 (consumed in region R + 1 / region 0 of the next block)
+    //   LDS  : region R reads the K fragment of key tile R + 2 (regions 6, 7: tiles 0, 1 of block n + 1) and the V^T fragment
+    //          that region R + 2 multiplies (regions 0..6: tile n - 1; region 7: the first fragment of tile n)
     //   sync : barrier(n) and the staging DMAs behind region 3 (every wave runs it for every tile of the workgroup)
     // Only two forms run more than a few times per pass: the unmasked pair (PAR 0 then PAR 1) of the steady state.  Every
     // other block (the second, an odd one out, diagonal / ragged blocks, the drain) runs the masked PAR = 0 form followed
     // by a swap of the two P^T buffers, so that block parity never has to be known at run time.  Blocks that have no
     // predecessor to finish multiply zeroed fragments (pf, vf start at zero), which keeps the forms few.
-    auto block8 = [&] __device__ (auto par_c, auto do_s_c, auto sl0_c, auto sl_c, auto pv_c, auto mask_c, auto first_c, bool do_sync, int n) {
+    // Fragments are read TWO regions ahead of their MFMAs (region R reads key tile R + 2 and the V^T fragment of region
+    // R + 2's product into the buffer region R has just consumed): an LDS read has a whole region to land instead of a few instructions.
+    // VRD = the V^T reads of regions 0..6 (tile n - 1), VRD7 = that of region 7 (first fragment of tile n, behind the address advance).
+    auto block8 = [&] __device__ (auto par_c, auto do_s_c, auto sl0_c, auto sl_c, auto pv_c, auto mask_c, auto first_c, auto vrd_c, auto vrd7_c, bool do_sync, int n) {
         constexpr int PAR = decltype(par_c)::value;
+        constexpr bool VRD = decltype(vrd_c)::value, VRD7 = decltype(vrd7_c)::value;
         constexpr bool DO_S = decltype(do_s_c)::value, SL0 = decltype(sl0_c)::value, SL = decltype(sl_c)::value;
         constexpr bool PV = decltype(pv_c)::value, FIRST = decltype(first_c)::value;
         const int key0 = n * kBN8;
         auto region = [&] __device__ (auto r_c) {
             constexpr int R = decltype(r_c)::value;
             __builtin_amdgcn_sched_barrier(0);
+            // the score MFMAs go first: their results are the next region's first VALU operands
+            if constexpr (DO_S) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s_acc[R & 1][qt] = mfma8(kf[(R & 1) % NFB], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+            }
             if constexpr (PV) {
                 constexpr int dt = (R == 0) ? 7 : R - 1;
                 constexpr int par = (R == 0) ? PAR : (PAR ^ 1);
@@ -315,18 +317,26 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
                 }
             }
             if constexpr (DO_S) {
-#pragma unroll
-                for (int qt = 0; qt < 2; ++qt) s_acc[R & 1][qt] = mfma8(kf[(R & 1) % NFB], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-                if constexpr (R == 7) advance_k();
-                read_k(IC<(R + 1) & 7>{}, IC<(R + 1) & 1>{});
+                if constexpr (R == 6) advance_k();
+                read_k(IC<(R + 2) & 7>{}, IC<R & 1>{});
             }
-            if constexpr (PV) read_v(IC<R>{}, IC<(R + 1) & 1>{});
+            if constexpr (R == 7 ? VRD7 : VRD) {
+                if constexpr (R == 7 && VRD) advance_v();         // (the fill block has no predecessor: its addresses already point at tile 0)
+                read_v(IC<(R + 1) & 7>{}, IC<R & 1>{});
+            }
             if constexpr (R == 0) {
                 if constexpr (SL0) sm_slice(mask_c, IC<PAR ^ 1>{}, IC<7>{}, key0 - kBN8);
             } else if constexpr (SL) {
                 if constexpr (FIRST && R == 1) sm_set_reference(mask_c, key0);
                 sm_slice(mask_c, IC<PAR>{}, IC<R - 1>{}, key0);
             }
+#if !defined(FA8_NO_SGB)
+            if constexpr (DO_S && PV && SL && SL0) {       // steady form: 4 x {1 MFMA, DS reads, 5 VALU}
+#define FA8_GRP(NDS) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0); __builtin_amdgcn_sched_group_barrier(0x402, 5, 0)
+                FA8_GRP(1); FA8_GRP(1); FA8_GRP(2); FA8_GRP(2);
+#undef FA8_GRP
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (R == 3) {
                 if (do_sync) sync_and_stage(n);
@@ -352,29 +362,27 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     int j = 0;
     if (NT > 0) {
         read_k(IC<0>{}, IC<0>{});
+        read_k(IC<1>{}, IC<1>{});
         // block 0 (pipeline fill): scores and slices only; its first key tile fixes the reference
-        block8(IC<0>{}, Y{}, N_{}, Y{}, N_{}, Y{}, Y{}, true, 0);
+        block8(IC<0>{}, Y{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, true, 0);
         swap_pf();
         stage_k = (stage_k + 1) & (kStages - 1);
-        j = 1;                                         // (block 1 reads V(0): the first advance_v follows block 1)
+        j = 1;
         const int ja = min(mb, NT);
         for (; j + 1 < ja; j += 2) {                   // steady state: pairs of unmasked blocks
-            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, true, j);
+            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, Y{}, Y{}, true, j);
             stage_k = (stage_k + 1) & (kStages - 1);
-            advance_v();
-            block8(IC<1>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, true, j + 1);
+            block8(IC<1>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, Y{}, Y{}, true, j + 1);
             stage_k = (stage_k + 1) & (kStages - 1);
-            advance_v();
         }
         for (; j < NT; ++j) {                          // an odd block out, diagonal / ragged blocks: masked form + buffer swap
-            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, Y{}, N_{}, true, j);
+            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, Y{}, N_{}, Y{}, Y{}, true, j);
             swap_pf();
             stage_k = (stage_k + 1) & (kStages - 1);
-            advance_v();
         }
         // drain, "block" NT: the last slice, P V of block NT - 1 (tiles 0..6) and of block NT - 2 (tile 7) ...
         const bool sync_d = j < nt;
-        block8(IC<0>{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, sync_d, j);
+        block8(IC<0>{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, N_{}, sync_d, j);
         if (sync_d) stage_k = (stage_k + 1) & (kStages - 1);
         ++j;
         // ... and tile 7 of block NT - 1 (its V^T fragment was read in region 7 above)
@@ -386,14 +394,12 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         stage_k = (stage_k + 1) & (kStages - 1);
     }
 
-    // ---- exact fallback (rare): per-block online softmax with running maximum and rescale, P = exp2(score - max + 7) <= 128
-    float l_part[2] = {l_sum[0], l_sum[1]};
+    // ---- exact fallback (rare): per-block online softmax with running maximum and rescale, P = exp2(score - max + 7) <= 128.
+    // Trigger: a P beyond e4m3's range turns into NaN in the conversion (v_cvt_pk_fp8_f32 under the default float mode:
+    // tools/probes/cvt_fp8_probe.cpp) and poisons the row's rounded sum on the matrix pipe -- no per-score bookkeeping.
+    float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     dma_wait<0>();
-#if defined(FA8_NOFALLBACK)
-    if (false) {
-#else
-    if (wg_any(!(peak < kPLimit8), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
-#endif
+    if (wg_any(!(l_acc[0][0] < kPLimit8 && l_acc[1][0] < kPLimit8), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
         constexpr int KO = 0, VO = VBASE;
         const int lane_f = lane_here();
         const int li = lane_f & 15, lg = lane_f >> 4;

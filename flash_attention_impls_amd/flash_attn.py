@@ -123,8 +123,9 @@ def load_library(path: str | None = None):
     with _lib_lock:
         if _lib_handle is not None and path is None:
             return _lib_handle
-        p = path or _build.LIB_PATH
-        if path is None and _build.is_stale():
+        env_path = os.environ.get("FA_MI355_LIB") if path is None else None   # developer aid: profile another build of the library
+        p = path or env_path or _build.LIB_PATH
+        if path is None and env_path is None and _build.is_stale():
             try:
                 _build.build()
             except Exception as e:  # noqa: BLE001

@@ -40,6 +40,9 @@ for (B, H, Hkv, S, Sk, D, causal, mul) in [
     ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
     q, k, v = [(t / s).to(torch.float8_e4m3fn) for t, s in zip(f32, ds)]
     o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    o_nolse = fa.flash_attn(q, k, v, causal, descale=ds)                 # the variant that forms no exact row sums
+    if not torch.equal(o, o_nolse):
+        print("BAD: output differs between the LSE and the no-LSE variant"); bad += 1
     ref, lse_ref = ref64(q, k, v, ds, causal)
     rel = float((o.double() - ref).norm() / ref.norm())
     mx = float((o.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
