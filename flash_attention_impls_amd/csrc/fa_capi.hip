@@ -48,6 +48,22 @@ int launch(const fa::FwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
+// 128-row workgroups (4 waves x 32 rows) of the 32x32x16 kernel: launches whose 256-row grid would leave CUs without work
+template <class T, int D, bool CAUSAL>
+int launch_rows128(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::lds_bytes<D>();
+    auto* kernel = &fa::fa_fwd_kernel<T, D, CAUSAL, 1, 4>;
+    struct Tag {};
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel<T, D, CAUSAL, 1, 4>), dim3(grid), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 // kernel on 16x16x32 MFMA tiles (fa_fwd_kernel16.hpp), compiled head_dim D = 128 or 64
 template <class T, bool CAUSAL, int D>
 int launch16(const fa::FwdParams& p, int grid, hipStream_t stream)
@@ -97,8 +113,14 @@ int launch8(const fa::FwdParams& p, int grid, hipStream_t stream)
 }
 
 template <class T, int D>
-int launch_c(const fa::FwdParams& p, int grid, bool causal, hipStream_t s)
+int launch_c(const fa::FwdParams& p, int grid, bool causal, int bm, hipStream_t s)
 {
+#if !defined(FA_MFMA32)
+    if constexpr (kQB == 1 && D == 64) {
+        if (bm == 128) return causal ? launch_rows128<T, D, true>(p, grid, s) : launch_rows128<T, D, false>(p, grid, s);
+    }
+#endif
+    (void)bm;
     // default: the 16x16x32 kernel; -DFA_MFMA32 (and the FA_QB variants) select the 32x32x16 kernel of fa_fwd_kernel.hpp
 #if !defined(FA_MFMA32)
     if constexpr (kQB == 1) {
@@ -155,19 +177,34 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
 
 // causal launches pair query blocks (nqb-1-t, t) per workgroup for equal work -- unless single blocks, longest first, are
 // expected to finish earlier (fa_capi::causal_unpaired: small grids, or a mostly empty last round of pairs)
-bool unpaired_for(int B, int H, int S, bool causal)
+bool unpaired_for(int B, int H, int S, bool causal, int bm = fa::kBM)
 {
-    const long long nqb = (S + fa::kBM - 1) / fa::kBM;
+    const long long nqb = (S + bm - 1) / bm;
     return causal && fa_capi::causal_unpaired((long long)B * H, nqb);
 }
 
-int grid_for(int B, int H, int S, bool causal)
+int grid_for(int B, int H, int S, bool causal, int bm = fa::kBM)
 {
     const long long bh = (long long)B * H;
-    const long long nqb = (S + fa::kBM - 1) / fa::kBM;
-    const long long per_head = (causal && !unpaired_for(B, H, S, causal)) ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
+    const long long nqb = (S + bm - 1) / bm;
+    const long long per_head = (causal && !unpaired_for(B, H, S, causal, bm)) ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
     const long long g = fa_capi::grid_blocks(bh, per_head, fa_capi::head_split(bh, per_head));   // (virtual) heads padded to a multiple of 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
+}
+
+// Query rows per workgroup of a 16-bit launch: 256 (8 waves), or 128 (4 waves, head_dim <= 64 only) when the 256-row grid
+// would leave a quarter or more of the 256 CUs without a workgroup -- small launches are latency-bound, and a CU that holds
+// no workgroup contributes nothing (cfg2: 128 workgroups of 256 rows -> 256 of 128 rows)
+int rows_per_wg(int B, int H, int S, int D, bool causal)
+{
+#if defined(FA_MFMA32) || FA_QB != 1 || defined(FA_NO_ROWS128)
+    (void)B; (void)H; (void)S; (void)D; (void)causal;
+    return fa::kBM;
+#else
+    if (D > 64 || S <= 128) return fa::kBM;
+    const int g = grid_for(B, H, S, causal);
+    return (g > 0 && g <= 192) ? 128 : fa::kBM;
+#endif
 }
 
 }  // namespace
@@ -191,8 +228,9 @@ int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* g
 {
     if (!fa_supported(dtype, D)) return fail(FA_ERR_BAD_HEAD_DIM, "unsupported (dtype=%d, head_dim=%d)", dtype, D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape");
-    if (grid) *grid = grid_for(B, H, S, causal != 0);
-    if (block) *block = kThreads;
+    const int bm = (dtype == FA_DTYPE_FP8_E4M3 && D > 64) ? fa::kBM : rows_per_wg(B, H, S, D, causal != 0);
+    if (grid) *grid = grid_for(B, H, S, causal != 0, bm);
+    if (block) *block = bm == 128 ? 256 : kThreads;
     if (lds_bytes) *lds_bytes = (D > 64) ? fa::lds_bytes<128>() : fa::lds_bytes<64>();
     return FA_OK;
 }
@@ -235,10 +273,11 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.B = B; p.H = H; p.S = S; p.Sk = S_k;
     p.G = H / H_kv;
     p.dv = D;
-    p.nqb = (S + fa::kBM - 1) / fa::kBM;
-    p.unpaired = unpaired_for(B, H, S, causal != 0) ? 1 : 0;
+    const int bm = rows_per_wg(B, H, S, D, causal != 0);
+    p.nqb = (S + bm - 1) / bm;
+    p.unpaired = unpaired_for(B, H, S, causal != 0, bm) ? 1 : 0;
     {
-        const long long nqb_ = (S + fa::kBM - 1) / fa::kBM;
+        const long long nqb_ = (S + bm - 1) / bm;
         p.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !p.unpaired) ? (nqb_ + 1) / 2 : nqb_);
     }
     p.bh = B * H;
@@ -268,14 +307,14 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.scale_log2 = p.scale * 1.4426950408889634f;
     p.out_scale = dvv;
 
-    const int grid = grid_for(B, H, S, causal != 0);
+    const int grid = grid_for(B, H, S, causal != 0, bm);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool c = causal != 0;
     if (dtype == FA_DTYPE_BF16)
-        return D > 64 ? launch_c<fa::TypeBF16, 128>(p, grid, c, s) : launch_c<fa::TypeBF16, 64>(p, grid, c, s);
+        return D > 64 ? launch_c<fa::TypeBF16, 128>(p, grid, c, bm, s) : launch_c<fa::TypeBF16, 64>(p, grid, c, bm, s);
     if (dtype == FA_DTYPE_FP16)
-        return D > 64 ? launch_c<fa::TypeF16, 128>(p, grid, c, s) : launch_c<fa::TypeF16, 64>(p, grid, c, s);
+        return D > 64 ? launch_c<fa::TypeF16, 128>(p, grid, c, bm, s) : launch_c<fa::TypeF16, 64>(p, grid, c, bm, s);
     return fail(FA_ERR_BAD_DTYPE, "dtype %d not compiled", dtype);
 }
 

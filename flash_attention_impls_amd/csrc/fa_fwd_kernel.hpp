@@ -262,10 +262,14 @@ struct SmState {
     float rs0, rs1;   // this lane's partial row sums (two independent chains)
 };
 
-template <class T, int D, bool CAUSAL, int QB>
-__global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const FwdParams p)
+// NWV = waves per workgroup: 8 / QB by default (a 256-row query block); NWV = 4 with QB = 1 gives 128-row workgroups for
+// launches that would otherwise leave CUs without a workgroup (the host picks: fa_capi.hip, small_rows_for)
+template <class T, int D, bool CAUSAL, int QB, int NWV = 8 / QB>
+__global__ __launch_bounds__(64 * NWV, (NWV * QB == 8) ? 2 / QB : 2) void fa_fwd_kernel(const FwdParams p)
 {
-    constexpr int NWAVES = 8 / QB;
+    constexpr int NWAVES = NWV;
+    constexpr int kBM = 32 * QB * NWV;         // query rows per workgroup (shadows the namespace-level 256)
+    constexpr bool SIMD_PAIRS = NWV == 8 && QB == 1;   // waves w and w + 4 share a SIMD
     constexpr int KS = D / 16;                 // k-steps of the QK^T product
     constexpr int DB = D / 32;                 // 32-wide head_dim blocks of O^T
     constexpr int ROWB = D * 2;                // bytes per K/V row in LDS
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
     // so that the causal diagonal tile is balanced across SIMDs.  QB = 2: wave w owns row blocks 2w and 2w+1.
     int q0[QB];
     if constexpr (QB == 1) {
-        q0[0] = qb * kBM + (CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave) * 32;
+        q0[0] = qb * kBM + ((CAUSAL && SIMD_PAIRS) ? (wave < 4 ? wave : 11 - wave) : wave) * 32;
     } else {
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) q0[qi] = qb * kBM + (wave * QB + qi) * 32;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(64 * (8 / QB), 2 / QB) void fa_fwd_kernel(const Fwd
 #pragma unroll
         for (int qi = 0; qi < QB; ++qi) {
             int row0;
-            if constexpr (QB == 1) row0 = qblk * kBM + (CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave) * 32;
+            if constexpr (QB == 1) row0 = qblk * kBM + ((CAUSAL && SIMD_PAIRS) ? (wave < 4 ? wave : 11 - wave) : wave) * 32;
             else row0 = qblk * kBM + (wave * QB + qi) * 32;
             const int qrow = row0 + r;
             // rows past the end of the sequence get an offset outside the descriptor: they read as zero

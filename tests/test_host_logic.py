@@ -84,6 +84,11 @@ def test_launch_info_geometry():
     assert (g.value, b.value, l.value) == (8 * 32 * 8, 512, 131072)      # cfg3: causal pairs of query blocks; 4-stage K and V rings of 16 KiB tiles
     assert lib.fa_fwd_launch_info(1, 3, 77, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
     assert (g.value, b.value, l.value) == (8, 512, 65536)                # heads padded to 8 XCD groups
+    # small head_dim-64 launches get 128-row workgroups (4 waves) when 256-row ones would leave CUs empty: cfg2
+    assert lib.fa_fwd_launch_info(4, 8, 1024, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
+    assert (g.value, b.value, l.value) == (4 * 8 * 8, 256, 65536)
+    assert lib.fa_fwd_launch_info(8, 32, 4096, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
+    assert (g.value, b.value) == (8 * 32 * 16, 512)                      # a grid that fills the chip keeps 256 rows
     assert lib.fa_fwd_launch_info(1, 1, 8, 40, 0, 0, None, None, None) == -2
 
 
