@@ -98,3 +98,63 @@ def test_cfg5_causal_sampled_rows(cfg5):
         got = oc[b, h, int(r)].double().cpu().numpy()
         assert np.linalg.norm(got - ref) <= FP8_REL_FRO * max(np.linalg.norm(ref), 1e-6), (b, h, r)
         assert abs(float(lsec[b, h, int(r)]) - lse_ref) <= 1e-3 * max(1.0, abs(lse_ref))
+
+
+# ------------------------------------------------------------------ the fp8 kernel's rare paths and variants (small shapes)
+def _fp8_case(B, H, Hkv, S, Sk, Dh, seed, spike=None):
+    g = torch.Generator().manual_seed(seed)
+    f32 = [torch.randn(B, H, S, Dh, generator=g), torch.randn(B, Hkv, Sk, Dh, generator=g), torch.randn(B, Hkv, Sk, Dh, generator=g)]
+    if spike is not None:                       # key `spike[0]` aligned with query `spike[1]`: a score far above the row's first keys
+        f32[1][:, :, spike[0]] = f32[0][:, : Hkv, spike[1]] * spike[2]
+    ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q, k, v = [(t / s).to(torch.float8_e4m3fn).cuda() for t, s in zip(f32, ds)]
+    return q, k, v, ds
+
+
+def _ref64(q, k, v, ds, causal):
+    from oracle import attn_oracle as orc
+    G = q.shape[1] // k.shape[1]
+    deq = [t.float().cpu() * s for t, s in zip((q, k, v), ds)]
+    deq[1], deq[2] = deq[1].repeat_interleave(G, 1), deq[2].repeat_interleave(G, 1)
+    return orc.naive_attention_f64(*[t.numpy() for t in deq], causal=causal)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("key,query", [(700, 900), (130, 200), (5, 1000)])
+def test_fp8_forced_exact_fallback(causal, key, query):
+    """A P beyond e4m3's range (here: one key whose score lies tens of binades above the reference fixed from the row's first 16 keys)
+    turns into NaN in the conversion, poisons that row's sum on the matrix pipe and sends the workgroup to the exact
+    running-maximum loop: the output must come out as accurate as on ordinary data, for every row of the workgroup."""
+    q, k, v, ds = _fp8_case(1, 2, 2, 1024, 1024, 128, seed=key, spike=(key, query, 6.0))
+    o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    ref, lse_ref = _ref64(q, k, v, ds, causal)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    of = o.double().cpu().numpy()
+    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    assert np.abs(of - ref).max() <= 7e-2 * max(1.0, np.abs(ref).max())
+    assert np.abs(lse.double().cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+    if not causal or key <= query:
+        assert lse_ref[0, 0, query] > 30.0                   # the spike really is there
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2, 128, 128, 128), (2, 3, 3, 333, 333, 128), (1, 4, 2, 777, 777, 128), (1, 2, 2, 1, 1, 128),
+                                   (1, 2, 1, 1030, 1030, 96), (1, 2, 2, 256, 1024, 128), (1, 2, 2, 1024, 300, 80)])
+@pytest.mark.parametrize("causal", [False, True])
+def test_fp8_shapes_and_lse_variants(shape, causal):
+    """Ragged lengths, grouped heads, other head dims (80, 96: zero-filled through the buffer bounds), own key length; the
+    kernel variant that forms no exact row sums (no LSE asked for) returns bitwise the same O as the one that does."""
+    B, H, Hkv, S, Sk, Dh = shape
+    q, k, v, ds = _fp8_case(B, H, Hkv, S, Sk, Dh, seed=S + Dh + causal)
+    o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    o2 = fa.flash_attn(q, k, v, causal, descale=ds)
+    assert torch.equal(o, o2)
+    ref, lse_ref = _ref64(q, k, v, ds, causal)
+    of = o.double().cpu().numpy()
+    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * max(np.linalg.norm(ref), 1e-9)
+    assert np.abs(of - ref).max() <= 7e-2 * max(1.0, np.abs(ref).max())
+    fin = np.isfinite(lse_ref)
+    got = lse.double().cpu().numpy()
+    assert np.array_equal(np.isinf(got), ~fin)               # rows without keys: O = 0, LSE = -inf
+    if fin.any():
+        assert np.abs(got[fin] - lse_ref[fin]).max() <= 1e-3 * max(1.0, np.abs(lse_ref[fin]).max())
+    assert (of[~fin] == 0).all()
