@@ -444,6 +444,14 @@ int fa_fwd_fp8_ex(const void* q, const void* k, const void* v, void* o, float* l
     return causal ? launch16_qk8<true>(p, grid, s) : launch16_qk8<false>(p, grid, s);
 }
 
+#if defined(FA_STAMP)
+// diagnostic build (tools/stamps.py): copy the stamp sums of the last head_dim-128 forward launches to the host
+extern "C" int fa_debug_read_stamps(void* dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::g_fa_stamp), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 // 1 if the fp8 entry runs P V on fp8 MFMAs too (head_dim > 64), 0 if that product runs on bf16 MFMAs
 int fa_fp8_pv_native(void)
 {

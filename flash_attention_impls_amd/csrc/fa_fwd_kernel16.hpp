@@ -30,6 +30,21 @@
 
 namespace fa {
 
+#if defined(FA_STAMP)
+// Diagnostic build only (-DFA_STAMP; never shipped, never timed; tools/stamps.py reads it): per-wave cycle sums by s_memtime
+// stamps (cdna_hip_programming.md section 7, In-kernel stamps) of (a) the three segments of a steady-state tile -- even block,
+// wait + barrier, odd block with its staging DMAs -- and (b) the phases of a pass.  The stamps drain the LDS reads the real
+// kernel keeps in flight across block boundaries: read the SHARES, not the lengths.
+__device__ unsigned long long g_fa_stamp[8192 * 8 * 24];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
 // V tile swizzle for the 16x16x32 transposed reads: a 32-lane half reads 8 consecutive keys x 32 bytes;
 // XOR the 32-byte segment index with (key & 7) so they fill one 256-byte bank row.
 __device__ __forceinline__ int v_swz16(int row, int ch) { return ch ^ ((row & 7) << 1); }
@@ -79,6 +94,16 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(FA_STAMP)
+    unsigned long long st_e = 0, st_w = 0, st_o = 0, st_n = 0;
+    const unsigned long long st_t0 = stamp_now();
+    unsigned long long st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0) :: "memory");
+    unsigned long long st_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = st_t0;
+#define FA_PHASE(K) do { const unsigned long long t_ = stamp_now(); st_ph[K] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define FA_PHASE(K) do {} while (0)
+#endif
 
     // ---- workgroup -> (head, query block(s)): see fa_fwd_kernel.hpp
     // causal: a workgroup takes the query-block pair (nqb-1-t, t) -- equal work for every workgroup -- unless the launch is
@@ -143,7 +168,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             }
         }
     };
+    FA_PHASE(8);                // (diagnostic) kernel entry: parameters, workgroup decode, descriptors
     if (pass == 0) load_q(qb, lane);
+    FA_PHASE(9);                // (diagnostic) Q loads issued
 
     // ---- K/V staging by LDS-DMA (see fa_fwd_kernel.hpp); V uses the 16x16 swizzle
     constexpr int VBASE = kStages * TILE;
@@ -475,10 +502,15 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         if constexpr (LEAN) dma_v(2, 2 * TILE);
         else dma_v(1, TILE);
     };
+    FA_PHASE(10);               // (diagnostic) offsets, addresses, accumulator init
     if (pass == 0) issue_prologue();
+    FA_PHASE(11);               // (diagnostic) prologue DMAs issued
     if constexpr (LEAN) dma_wait<2 * (CPTK + CPT)>();
-    else dma_wait<2 * CPTK + CPT>(); // this wave's pieces of K(0), V(0) have landed ...
+    // this wave's pieces of K(0) (and, older, its Q fragments) have landed; V(0) may still be in flight: its first reader is
+    // the fragment prefetch at the end of block 1, behind iteration 0's own wait and barrier, which cover it
+    else dma_wait<2 * CPTK + 2 * CPT>();
     __syncthreads();            // ... and every wave's are visible
+    FA_PHASE(0);                // pass start -> first tiles visible (what remains of it: the wait for Q / K(0) and the barrier)
 
     int dk = 0, dv = 0;                            // address deltas used by the odd block of iteration j
     auto begin_iter = [&](int j) {
@@ -602,6 +634,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, N{}, Y{}, Y{}, IC<-1>{}, 1, dk, dv);
         end_iter();
         j = 1;
+        FA_PHASE(1);            // fill iteration
         const int ja = min(jm, NT);
         // steady state, no masking, four tiles per trip: the ring stage of every LDS access is an immediate
         // (no address arithmetic in the loop).  j = 1 on entry, so the stages run 1, 2, 3, 0.
@@ -611,6 +644,25 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             for (int ks = 0; ks < KS; ++ks) ka[ks] -= sk0;           // stage-0 bases
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) va[dt] -= sv0;
+#if defined(FA_STAMP)
+#define FA_STAMPED_TILE(ST, JJ, NN) do { \
+                const unsigned long long t0 = stamp_now(); \
+                block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<ST>{}, NN, 0, 0); \
+                const unsigned long long t1 = stamp_now(); \
+                FA_SYNC_STAGE_C(IC<ST>{}, JJ); \
+                const unsigned long long t2 = stamp_now(); \
+                FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<ST>{}, NN + 1, 0, 0); \
+                const unsigned long long t3 = stamp_now(); \
+                st_e += t1 - t0; st_w += t2 - t1; st_o += t3 - t2; st_n += 1; } while (0)
+            for (; j + 4 <= ja; j += 4) {
+                FA_STAMPED_TILE(1, j, 2 * j);
+                FA_STAMPED_TILE(2, j + 1, 2 * j + 2);
+                FA_STAMPED_TILE(3, j + 2, 2 * j + 4);
+                FA_STAMPED_TILE(0, j + 3, 2 * j + 6);
+            }
+#undef FA_STAMPED_TILE
+            st_last = stamp_now();
+#else
             for (; j + 4 <= ja; j += 4) {
                 block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j, 0, 0);
                 FA_SYNC_STAGE_C(IC<1>{}, j);
@@ -625,11 +677,13 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
                 FA_SYNC_STAGE_C(IC<0>{}, j + 3);
                 FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<0>{}, 2 * j + 7, 0, 0);
             }
+#endif
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) ka[ks] += sk0;           // back to stage-carrying addresses (stage_k unchanged)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) va[dt] += sv0;
         }
+        FA_PHASE(2);            // unrolled steady loop
         for (; j < ja; ++j) {                      // steady state, no masking
             begin_iter(j);
             block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j, 0, 0);
@@ -637,6 +691,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
             end_iter();
         }
+        FA_PHASE(3);            // leftover unmasked tiles (generic addresses)
         for (; j < NT; ++j) {                      // steady state with masking (diagonal / ragged tiles)
             begin_iter(j);
             block(half0_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j, 0, 0);
@@ -644,6 +699,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
             end_iter();
         }
+        FA_PHASE(4);            // masked tiles
         begin_iter(j);                             // iteration NT (pipeline drain)
         block(half0_t{}, N{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j, 0, 0);
         if (j < nt) sync_and_stage(j);
@@ -659,6 +715,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         end_iter();
     }
     }  // !LEAN
+    FA_PHASE(5);                // drain, staging-only tiles
 
     // ---- exact fallback (rare): plain per-tile online softmax with running max and rescale
     // A lane's row-sum share below kPLimit bounds every P it produced (all terms are positive); NaN fails the test.
@@ -772,6 +829,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         __syncthreads();                       // every wave is done with the fallback's LDS stages
     }
 
+    FA_PHASE(6);                // fallback check (two barriers)
     // ---- the next query block of a causal pair travels while this block's output is normalised and stored
     if (pass + 1 < n_pass) {
         issue_prologue();
@@ -812,7 +870,19 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             }
         }
     }
+    FA_PHASE(7);                // epilogue (and the next pass's prologue issue)
   }  // pass
+#undef FA_PHASE
+#if defined(FA_STAMP)
+    if (lane_here() == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = g_fa_stamp + ((size_t)blockIdx.x * 8 + wave) * 24;
+        unsigned long long st_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1) :: "memory");
+        d[0] = st_e; d[1] = st_w; d[2] = st_o; d[3] = st_n; d[4] = stamp_now() - st_t0; d[5] = st_rt1 - st_rt0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d[8 + i] = st_ph[i];
+    }
+#endif
 }
 
 }  // namespace fa

@@ -1,0 +1,53 @@
+"""Diagnostic: where a steady-state tile of the head_dim-128 forward spends its cycles, per wave (build with
+tools/build_variant.sh stamp -DFA_STAMP; run on the GPU box: FA_MI355_LIB=build/libstamp.so python tools/stamps.py [--causal 0])."""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+import flash_attention_impls_amd as fa
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--causal", type=int, default=0)
+ap.add_argument("--B", type=int, default=8)
+ap.add_argument("--H", type=int, default=32)
+ap.add_argument("--S", type=int, default=4096)
+a = ap.parse_args()
+lib = fa.load_library()
+lib.fa_debug_read_stamps.restype = ctypes.c_int
+lib.fa_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+q, k, v = (torch.randn(a.B, a.H, a.S, 128, device="cuda").to(torch.bfloat16) for _ in range(3))
+for _ in range(30):
+    fa.flash_attn(q, k, v, bool(a.causal))
+torch.cuda.synchronize()
+n_wg = min(8192, a.B * a.H * ((a.S + 255) // 256) // (2 if a.causal else 1))
+buf = np.zeros((n_wg, 8, 24), dtype=np.uint64)
+rc = lib.fa_debug_read_stamps(buf.ctypes.data, buf.nbytes)
+assert rc == 0, rc
+f = buf.astype(np.float64)
+tiles = f[:, :, 3]
+ok = tiles > 0
+print(f"workgroups {n_wg}, stamped tiles per wave: mean {tiles[ok].mean():.1f}")
+print("wave   even-block   wait+barrier   odd-block(+DMA)   total   [cycles per tile, mean over workgroups]")
+for w in range(8):
+    m = ok[:, w]
+    e, wt, o = [(f[m, w, i] / tiles[m, w]).mean() for i in range(3)]
+    print(f"{w:4d}   {e:10.0f}   {wt:12.0f}   {o:15.0f}   {e + wt + o:7.0f}")
+e, wt, o = [(f[:, :, i][ok] / tiles[ok]).mean() for i in range(3)]
+print(f" all   {e:10.0f}   {wt:12.0f}   {o:15.0f}   {e + wt + o:7.0f}   wait share {wt / (e + wt + o):.3f}")
+tot = f[:, :, 4][ok]
+steady = (f[:, :, 0] + f[:, :, 1] + f[:, :, 2])[ok]
+rt = f[:, :, 5][ok]
+print(f"whole kernel per wave: {tot.mean():.0f} cycles, of which the stamped steady loop {steady.mean():.0f} ({steady.mean() / tot.mean():.3f}); "
+      f"outside it {tot.mean() - steady.mean():.0f} cycles per workgroup; shader clock {tot.mean() / rt.mean() * 100:.0f} MHz (s_memtime / s_memrealtime x 100 MHz)")
+names = ["pass start -> first tiles visible", "fill iteration", "unrolled steady loop", "leftover unmasked tiles", "masked tiles",
+         "drain + staging-only tiles", "fallback check", "epilogue (+ next prologue issue)",
+         "  entry: parameters, decode, descriptors", "  Q loads issued", "  offsets, addresses, accumulator init", "  prologue DMAs issued"]
+print("(the first phase below is what remains after the four indented entry sub-phases: the wait for Q / K(0) and the barrier)")
+print("phases, cycles per workgroup (sum over its passes), mean over waves [older waves 0-3 | younger 4-7]:")
+for i, nme in enumerate(names):
+    print(f"  {nme:36s} {f[:, :, 8 + i][ok].mean():9.0f}   [{f[:, :4, 8 + i].mean():9.0f} | {f[:, 4:, 8 + i].mean():9.0f}]")
