@@ -17,8 +17,10 @@ LIB_NAME = "libfa_mi355.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
 SOURCES = [os.path.join(CSRC, "fa_capi.hip"), os.path.join(CSRC, "fa_bwd_capi.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, n) for n in ("fa_fwd_kernel.hpp", "fa_fwd_kernel16.hpp", "fa_bwd_kernel.hpp", "fa_bwd_dkdv_kernel.hpp",
-                                                  "fa_capi_common.hpp")] + \
+# every file under csrc/ is a dependency (kernel headers are included from the two sources above): a header added later is
+# picked up without touching this list, and the digest below covers exactly what the compiler reads
+DEPS = SOURCES + sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC)
+                        if n.endswith((".hpp", ".h", ".hip")) and os.path.join(CSRC, n) not in SOURCES) + \
     [os.path.join(PKG_DIR, "..", "include", "fa_mi355.h")]
 
 # -fno-slp-vectorize: SLP packs the softmax's scalar f32 adds into v_pk_add_f32 chains placed behind the

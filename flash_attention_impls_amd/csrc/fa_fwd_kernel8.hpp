@@ -15,8 +15,10 @@
 //     ds_read_b64_tr_b8 per head_dim tile, each gathering 8 key rows (key tiles 2 m and 2 m + 1) x 16 columns
 //     (tools/probes/ds_read_tr8_probe.cpp: lane 2 q + p of a 16-lane group supplies the address of row q, lane i receives
 //     column i of the 8 rows);
-//   * P in e4m3: P = exp2(score - reference) with the reference fixed from the row's first 16 keys (bias 0), so typical P lies
-//     in 2^-7 .. 2^3; a P beyond e4m3's range converts to NaN, which poisons the row's sum on the matrix pipe and sends the
+//   * P in e4m3: P = exp2(score - reference + b) with the reference fixed from the row's first 16 keys and b (0 .. 8) placing
+//     e4m3's 2^-9 .. 448 window by how far that reference stands out of its own key tile (kGapFree8 below: ordinary rows get
+//     b ~ 0.5 and typical P in 2^-7 .. 2^4, a row led by a dominant early key gets b = 8); a P beyond e4m3's
+//     range converts to NaN, which poisons the row's sum on the matrix pipe and sends the
 //     workgroup to the exact loop (running maximum, P <= 128).  O is normalised by the sum of the ROUNDED P (from a "ones"
 //     head_dim tile on the matrix pipe); the LSE comes from the exact fp32 sum, formed only when an LSE is asked for.
 //     The e4m3 rounding of P (3 mantissa bits) is the accuracy cost of this kernel: ~2.7 % relative Frobenius error
@@ -30,7 +32,20 @@
 namespace fa {
 
 constexpr int kBN8 = 128;                      // keys per tile (= per block) of the fp8 kernel
-constexpr float kPBias8 = 0.0f;                // log2 offset of the softmax reference (P of the reference score = 2^-bias)
+// Where a row's P sit in e4m3 (2^-9 .. 448, full precision from 2^-6 up).  The softmax reference of a row is the maximum mx of
+// its first 16 keys and is shown to e4m3 as P(mx) = 2^b, b = clamp(gap - kGapFree8, 0, kPRefTop8) with gap = mx - (mean of those
+// 16 scores), in binades: the top of the window stands 8.86 + kGapFree8 binades above the MEAN of the first key tile (7.5 sigma on
+// N(0,1) data; measured on config 5's shard: kGapFree8 = 1 costs 2.6 % in workgroups sent to the exact loop, 2 costs 0.4 %, and
+// a max-anchored b = 3 sends 14 % of the workgroups there: -25 %), but never lower than just above mx itself -- a dominant early key (an "attention sink") then sits at the top of e4m3
+// and the many small terms under it, which together can weigh as much as the sink, stay in full precision down to 14.8 binades
+// below it.  A score above the window converts to NaN and sends the workgroup to the exact loop; a term 9 + b binades below the
+// reference is rounded to zero.  (The usual running-maximum fp8 softmax, P <= 1, drops terms 10 binades below the row maximum.)
+#ifndef FA8_GAP_FREE
+#define FA8_GAP_FREE 2.0f
+#endif
+constexpr float kGapFree8 = FA8_GAP_FREE;
+constexpr float kPRefTop8 = 8.0f;
+constexpr float kGapFloor8 = 12.0f;            // a score further than this below mx counts as mx - 12 in the mean (one very low key must not move the window)
 constexpr float kPLimit8 = 1e30f;              // a rounded row sum not below this (i.e. NaN: some P left e4m3's range) -> exact fallback
 
 // 16-byte-chunk swizzles of the 128-byte rows (two rows per 256-byte bank row)
@@ -225,24 +240,35 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, pf[par][qt][kt], false), true);
         }
     };
-    // the first key tile of a row's first block fixes its softmax reference
+    // the first key tile of a row's first block fixes its softmax reference and the place of its e4m3 window (kGapFree8 above)
     auto sm_set_reference = [&] __device__ (auto mask_c, int key0) {
         constexpr bool MASK = decltype(mask_c)::value;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = -INFINITY;
+            float mx = -INFINITY, cnt = 0.f;
             const int lim = limq[qt] - key0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = s_acc[0][qt][e];
-                if constexpr (MASK) {
-                    if (e > lim) v = -INFINITY;
-                }
-                mx = fmaxf(mx, v);
+                bool in = true;
+                if constexpr (MASK) in = (e <= lim);
+                mx = in ? fmaxf(mx, s_acc[0][qt][e]) : mx;
+                cnt += in ? 1.f : 0.f;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            m_c[qt] = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, kPBias8);
+            mx = fmaxf(mx, __shfl_xor(mx, 16));   cnt += __shfl_xor(cnt, 16);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));   cnt += __shfl_xor(cnt, 32);
+            const float floor_s = mx - kGapFloor8 * __builtin_amdgcn_rcpf(c);
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bool in = true;
+                if constexpr (MASK) in = (e <= lim);
+                sum += in ? fmaxf(s_acc[0][qt][e], floor_s) : 0.f;
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float gap = (mx - sum * __builtin_amdgcn_rcpf(fmaxf(cnt, 1.f))) * c;          // 0 .. 12 binades
+            const float b = fminf(fmaxf(gap - kGapFree8, 0.f), kPRefTop8);                      // (a NaN gap gives 0)
+            m_c[qt] = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, -b);
         }
     };
 

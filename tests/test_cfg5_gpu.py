@@ -120,11 +120,11 @@ def _ref64(q, k, v, ds, causal):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("key,query", [(700, 900), (130, 200), (5, 1000)])
+@pytest.mark.parametrize("key,query", [(700, 900), (130, 200), (40, 1000)])
 def test_fp8_forced_exact_fallback(causal, key, query):
-    """A P beyond e4m3's range (here: one key whose score lies tens of binades above the reference fixed from the row's first 16 keys)
-    turns into NaN in the conversion, poisons that row's sum on the matrix pipe and sends the workgroup to the exact
-    running-maximum loop: the output must come out as accurate as on ordinary data, for every row of the workgroup."""
+    """A P beyond e4m3's range (here: one key, outside the row's first 16, whose score lies tens of binades above the reference
+    fixed from them) turns into NaN in the conversion, poisons that row's sum on the matrix pipe and sends the workgroup to the
+    exact running-maximum loop: the output must come out as accurate as on ordinary data, for every row of the workgroup."""
     q, k, v, ds = _fp8_case(1, 2, 2, 1024, 1024, 128, seed=key, spike=(key, query, 6.0))
     o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
     ref, lse_ref = _ref64(q, k, v, ds, causal)
@@ -135,6 +135,59 @@ def test_fp8_forced_exact_fallback(causal, key, query):
     assert np.abs(lse.double().cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
     if not causal or key <= query:
         assert lse_ref[0, 0, query] > 30.0                   # the spike really is there
+
+
+def _f64_attention(q, k, v, ds, causal=False):
+    deq = [t.double().cpu().numpy() * s for t, s in zip((q, k, v), ds)]
+    s = np.einsum("bhid,bhjd->bhij", deq[0], deq[1]) / math.sqrt(q.shape[-1])
+    if causal:
+        s = np.where(np.tril(np.ones(s.shape[-2:], dtype=bool)), s, -np.inf)
+    w = np.exp(s - s.max(-1, keepdims=True))
+    w /= w.sum(-1, keepdims=True)
+    return np.einsum("bhij,bhjd->bhid", w, deq[2]), s
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("sink_nats", [5.0, 8.0, 10.0])
+def test_fp8_attention_sink_keeps_the_small_terms(sink_nats, causal):
+    """P in e4m3 spans 2^-9 .. 448 only.  With one dominant early key (an "attention sink": key 0 scores `sink_nats` above the
+    rest for every query) the many small terms under it still carry a large share of the weight (1023 keys x e^-8 x e^(var/2) ~ the
+    sink's own weight) and must not fall into e4m3's subnormals: the kernel places each row's window by how far its reference
+    stands out of the first key tile (kGapFree8 / kPRefTop8), which is what this case exercises."""
+    Bn, Hh, Sn, Dh = 1, 2, 1024, 128
+    g = torch.Generator().manual_seed(int(sink_nats))
+    u = torch.randn(Dh, generator=g)
+    u *= math.sqrt(Dh) / u.norm()
+    qf = torch.randn(Bn, Hh, Sn, Dh, generator=g) + u
+    kf, vf = (torch.randn(Bn, Hh, Sn, Dh, generator=g) for _ in range(2))
+    kf[:, :, 0] = u * (sink_nats / math.sqrt(Dh))                  # score of key 0: sink_nats +- sink_nats / 11 for every query
+    f32 = [qf, kf, vf]
+    ds = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q, k, v = [(t / s).to(torch.float8_e4m3fn).cuda() for t, s in zip(f32, ds)]
+    o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    ref, s = _f64_attention(q, k, v, ds, causal)
+    w0 = np.exp(s[..., 0] - np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) - s.max(-1))
+    assert 0.02 < np.median(w0[..., 16:]) < 0.98                    # neither the sink nor the rest is negligible
+    of = o.double().cpu().numpy()
+    assert np.isfinite(of).all()
+    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    rows = np.linalg.norm(of - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), 1e-3)
+    assert np.quantile(rows, 0.99) <= 2 * FP8_REL_FRO
+    lse_ref = np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)
+    assert np.abs(lse.double().cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+def test_fp8_one_outlier_key_in_the_first_tile():
+    """Key 5 (inside the 16 keys that fix the references) is a 6x copy of query 1000: its score against the other queries is
+    N(0, 6^2) nats, so across the rows it is anything from far below to tens of binades above the rest.  Every row must stay
+    within the fp8 bound (rows where key 5 dominates by more than ~15 binades lose the other keys, whose weight is then < 3 %)."""
+    q, k, v, ds = _fp8_case(1, 2, 2, 1024, 1024, 128, seed=5, spike=(5, 1000, 6.0))
+    o = fa.flash_attn(q, k, v, False, descale=ds).double().cpu().numpy()
+    ref, _ = _f64_attention(q, k, v, ds)
+    assert np.isfinite(o).all()
+    assert np.linalg.norm(o - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    rows = np.linalg.norm(o - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), 1e-3)
+    assert np.quantile(rows, 0.99) <= 2 * FP8_REL_FRO and rows.max() <= 4 * FP8_REL_FRO
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 2, 128, 128, 128), (2, 3, 3, 333, 333, 128), (1, 4, 2, 777, 777, 128), (1, 2, 2, 1, 1, 128),

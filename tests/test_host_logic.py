@@ -306,3 +306,19 @@ def test_concurrent_builds_compile_once_and_staleness_is_by_content(tmp_path):
     assert log.read_text().count("call") == 1                    # one compile for four processes
     assert not _build.is_stale()
     assert fa.load_library(_build.LIB_PATH).fa_version() == 130
+
+
+def test_build_digest_covers_every_kernel_source():
+    """Every file the two translation units can include (all of csrc/, the public header) is a dependency: a change to any
+    kernel header must make the library stale and change the digest that stamps profiles/hbm_traffic.json.  (Round 2's fp8
+    kernel header was once missing from a hand-kept list: edits to it did not rebuild the library.)"""
+    import re
+    from flash_attention_impls_amd import _build
+    deps = {os.path.basename(d) for d in _build.DEPS}
+    on_disk = {n for n in os.listdir(_build.CSRC) if n.endswith((".hip", ".hpp", ".h"))}
+    assert on_disk <= deps and "fa_mi355.h" in deps
+    included = set()
+    for n in on_disk:
+        with open(os.path.join(_build.CSRC, n)) as f:
+            included |= set(re.findall(r'#include\s+"([^"]+)"', f.read()))
+    assert {os.path.basename(i) for i in included} <= deps, included
