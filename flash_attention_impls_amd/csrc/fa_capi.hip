@@ -18,6 +18,7 @@
 #include "fa_fwd_kernel.hpp"
 #include "fa_fwd_kernel16.hpp"
 #include "fa_fwd_kernel8.hpp"
+#include "fa_fwd_kernel_wide.hpp"
 
 // 32-row query blocks per wave: 1 = 8 waves per workgroup (two per SIMD), 2 = 4 waves (one per SIMD, 512 registers)
 #ifndef FA_QB
@@ -112,6 +113,22 @@ int launch8(const fa::FwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
+// head_dim 144 .. 256: the plain 128-row kernel of fa_fwd_kernel_wide.hpp
+template <class T, bool CAUSAL>
+int launch_wide(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::kWideLds;
+    auto* kernel = &fa::fa_fwd_kernel_wide<T, CAUSAL>;
+    struct Tag {};
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel_wide<T, CAUSAL>), dim3(grid), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 template <class T, int D>
 int launch_c(const fa::FwdParams& p, int grid, bool causal, int bm, hipStream_t s)
 {
@@ -192,6 +209,17 @@ int grid_for(int B, int H, int S, bool causal, int bm = fa::kBM)
     return g > 0x7FFFFFFFll ? -1 : (int)g;
 }
 
+// wide heads (head_dim > 128): one 128-row query block per workgroup, no pairing
+int grid_wide(int B, int H, int S, int* hsplit)
+{
+    const long long bh = (long long)B * H;
+    const long long nqb = (S + fa::kBMW - 1) / fa::kBMW;
+    const int hs = fa_capi::head_split(bh, nqb);
+    if (hsplit) *hsplit = hs;
+    const long long g = fa_capi::grid_blocks(bh, nqb, hs);
+    return g > 0x7FFFFFFFll ? -1 : (int)g;
+}
+
 // Query rows per workgroup of a 16-bit launch: 256 (8 waves), or 128 (4 waves, head_dim <= 64 only) when the 256-row grid
 // would leave a quarter or more of the 256 CUs without a workgroup -- small launches are latency-bound, and a CU that holds
 // no workgroup contributes nothing (cfg2: 128 workgroups of 256 rows -> 256 of 128 rows)
@@ -221,13 +249,21 @@ int fa_supported(int dtype, int head_dim)
     // every head_dim the reference accepts (D % 16 == 0, D <= 128: FA2-triton.py:178; its native dispatcher: 32, 64, 128,
     // flash_attn_cutlass.cu:530-543): D <= 64 runs on the head_dim-64 kernel, larger on the head_dim-128 kernel, with the
     // columns past D read as zeros by the hardware's buffer bounds check and never stored
-    return (head_dim >= 16 && head_dim <= 128 && head_dim % 16 == 0) ? 1 : 0;
+    // ... and, beyond the reference, 144 .. 256 for the 16-bit types (forward only; fa_fwd_kernel_wide.hpp)
+    const int top = (dtype == FA_DTYPE_FP8_E4M3) ? 128 : fa::kWideD;
+    return (head_dim >= 16 && head_dim <= top && head_dim % 16 == 0) ? 1 : 0;
 }
 
 int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* grid, int* block, int* lds_bytes)
 {
     if (!fa_supported(dtype, D)) return fail(FA_ERR_BAD_HEAD_DIM, "unsupported (dtype=%d, head_dim=%d)", dtype, D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape");
+    if (D > 128) {
+        if (grid) *grid = grid_wide(B, H, S, nullptr);
+        if (block) *block = 256;
+        if (lds_bytes) *lds_bytes = fa::kWideLds;
+        return FA_OK;
+    }
     const int bm = (dtype == FA_DTYPE_FP8_E4M3 && D > 64) ? fa::kBM : rows_per_wg(B, H, S, D, causal != 0);
     if (grid) *grid = grid_for(B, H, S, causal != 0, bm);
     if (block) *block = bm == 128 ? 256 : kThreads;
@@ -259,7 +295,7 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16 && dtype != FA_DTYPE_FP8_E4M3)
         return fail(FA_ERR_BAD_DTYPE, "unknown dtype code %d", dtype);
     if (!fa_supported(dtype, D))
-        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 128)", D);
+        return fail(FA_ERR_BAD_HEAD_DIM, "head_dim %d not supported (need D %% 16 == 0 and 16 <= D <= 256)", D);
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
     if (B == 0 || H == 0 || S == 0) return FA_OK;        // empty problem: nothing to do
     if (H_kv <= 0 || H % H_kv != 0)
@@ -273,9 +309,10 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.B = B; p.H = H; p.S = S; p.Sk = S_k;
     p.G = H / H_kv;
     p.dv = D;
-    const int bm = rows_per_wg(B, H, S, D, causal != 0);
+    const bool wide = D > 128;
+    const int bm = wide ? fa::kBMW : rows_per_wg(B, H, S, D, causal != 0);
     p.nqb = (S + bm - 1) / bm;
-    p.unpaired = unpaired_for(B, H, S, causal != 0, bm) ? 1 : 0;
+    p.unpaired = wide ? 1 : (unpaired_for(B, H, S, causal != 0, bm) ? 1 : 0);
     {
         const long long nqb_ = (S + bm - 1) / bm;
         p.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !p.unpaired) ? (nqb_ + 1) / 2 : nqb_);
@@ -307,10 +344,14 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.scale_log2 = p.scale * 1.4426950408889634f;
     p.out_scale = dvv;
 
-    const int grid = grid_for(B, H, S, causal != 0, bm);
+    const int grid = wide ? grid_wide(B, H, S, nullptr) : grid_for(B, H, S, causal != 0, bm);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool c = causal != 0;
+    if (wide) {
+        if (dtype == FA_DTYPE_BF16) return c ? launch_wide<fa::TypeBF16, true>(p, grid, s) : launch_wide<fa::TypeBF16, false>(p, grid, s);
+        return c ? launch_wide<fa::TypeF16, true>(p, grid, s) : launch_wide<fa::TypeF16, false>(p, grid, s);
+    }
     if (dtype == FA_DTYPE_BF16)
         return D > 64 ? launch_c<fa::TypeBF16, 128>(p, grid, c, bm, s) : launch_c<fa::TypeBF16, 64>(p, grid, c, bm, s);
     if (dtype == FA_DTYPE_FP16)

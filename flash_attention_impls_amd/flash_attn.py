@@ -30,6 +30,8 @@ from . import _build
 FA_DTYPE_BF16 = 0
 FA_DTYPE_FP16 = 1
 FA_DTYPE_FP8_E4M3 = 2
+REFERENCE_MAX_HEAD_DIM = 128      # FA2-triton.py:178; the backward kernels stop here too
+MAX_HEAD_DIM = 256                # forward, bf16 / fp16 (csrc/fa_fwd_kernel_wide.hpp)
 
 
 
@@ -199,8 +201,8 @@ def check_args(q, k, v) -> None:
             "flash_attn needs GPU (ROCm 'cuda') tensors; there is no CPU path "
             "(reference: assert q.is_cuda, FA2-triton.py:176)")
     D = q.shape[3]
-    if D % 16 != 0 or D > 128:                          # FA2-triton.py:178
-        raise FlashAttnArgumentError(f"head_dim must satisfy D % 16 == 0 and D <= 128; got {D}")
+    if D % 16 != 0 or D > MAX_HEAD_DIM:                 # FA2-triton.py:178 (its bound is 128; 144 .. 256 is this library's extension)
+        raise FlashAttnArgumentError(f"head_dim must satisfy D % 16 == 0 and D <= {MAX_HEAD_DIM}; got {D}")
 
 
 def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
@@ -300,6 +302,9 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     code = _dtype_code(q.dtype)
     if needs_grad and code == FA_DTYPE_FP8_E4M3:
         raise FlashAttnArgumentError("float8 inputs are forward-only (no backward kernel)")
+    if needs_grad and q.shape[3] > REFERENCE_MAX_HEAD_DIM:
+        raise FlashAttnArgumentError(f"head_dim {q.shape[3]} > {REFERENCE_MAX_HEAD_DIM} is forward-only (no backward kernel): "
+                                     "detach the inputs or run under torch.no_grad()")
     if descale is not None:
         # per-tensor dequantisation scales belong to float8 inputs; accepting them for 16-bit inputs on one path only
         # (the autograd Function takes none) would make the result depend on the grad mode
@@ -313,7 +318,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
         softmax_scale = 1.0 / math.sqrt(D_in)             # FA2-triton.py:183 (of the caller's head_dim)
     # Every head_dim the reference accepts (D % 16 == 0, D <= 128, :178) runs natively: the library picks the head_dim-64
     # or head_dim-128 kernel and the hardware's buffer bounds check supplies zeros for the columns past D (no padded
-    # copies on the host, nothing extra stored).
+    # copies on the host, nothing extra stored).  144 .. 256 run forward-only on the wide-head kernel.
     D = D_in
     if not lib.fa_supported(code, D):
         raise FlashAttnArgumentError(f"no gfx950 kernel for dtype={q.dtype}, head_dim={D}")

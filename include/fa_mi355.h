@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 130          /* 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
+#define FA_VERSION 131          /* 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -62,7 +62,9 @@ extern "C" {
 int fa_version(void);
 
 /* 1 if (dtype, head_dim) is served: dtype as below, head_dim % 16 == 0 and 16 <= head_dim <= 128 (what the reference
- * accepts, FA2-triton.py:178; head_dim <= 64 runs on the head_dim-64 kernel, larger on the head_dim-128 kernel). */
+ * accepts, FA2-triton.py:178; head_dim <= 64 runs on the head_dim-64 kernel, larger on the head_dim-128 kernel), and --
+ * beyond the reference, forward only, bf16 / fp16 -- 144 <= head_dim <= 256 (a plain 128-row kernel; the backward entry
+ * points reject head_dim > 128). */
 int fa_supported(int dtype, int head_dim);
 
 /* Message describing the last error on the calling thread ("" if none). */

@@ -55,7 +55,7 @@ def assert_grad_close(got, ref, dt, what):
 # ------------------------------------------------------------------ golden vectors (from the reference)
 @pytest.mark.parametrize("name", golden_bwd_names())
 def test_bwd_golden_vectors(name):
-    assert fa.load_library().fa_version() == 130
+    assert fa.load_library().fa_version() == 131
     d = load_golden(name)
     q, k, v, do = [golden_torch(d, n, "cuda") for n in ("q", "k", "v", "do")]
     o, dq, dk, dv = hip_grads(q, k, v, do, bool(d["causal"]))

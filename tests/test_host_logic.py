@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             "fa_fwd_launch_info", "fa_fwd_fp8", "fa_fp8_workspace_bytes"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
-    assert lib.fa_version() == 130
+    assert lib.fa_version() == 131
     assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
 
 
@@ -45,8 +45,11 @@ def test_supported_matrix():
         # every head_dim the reference accepts: D % 16 == 0, D <= 128 (FA2-triton.py:178; dispatcher 32/64/128)
         for d in (16, 32, 48, 64, 80, 96, 112, 128):
             assert lib.fa_supported(dt, d) == 1
-        for d in (0, 8, 24, 72, 144, 256):
+        for d in (0, 8, 24, 72, 136, 264, 272, 512):
             assert lib.fa_supported(dt, d) == 0
+        # beyond the reference: 144 .. 256 forward-only on the 16-bit types
+        for d in (144, 160, 192, 208, 256):
+            assert lib.fa_supported(dt, d) == (1 if dt in (0, 1) else 0)
     assert lib.fa_supported(7, 128) == 0
 
 
@@ -90,6 +93,10 @@ def test_launch_info_geometry():
     assert lib.fa_fwd_launch_info(8, 32, 4096, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
     assert (g.value, b.value) == (8 * 32 * 16, 512)                      # a grid that fills the chip keeps 256 rows
     assert lib.fa_fwd_launch_info(1, 1, 8, 40, 0, 0, None, None, None) == -2
+    # wide heads: 128-row workgroups of 4 waves, two stages of 32 KiB K and V tiles, no causal pairing
+    assert lib.fa_fwd_launch_info(2, 8, 1000, 256, 1, 1, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
+    assert (g.value, b.value, l.value) == (2 * 8 * 8, 256, 131072)
+    assert lib.fa_fwd_launch_info(1, 1, 8, 256, 2, 0, None, None, None) == -2          # fp8 stops at head_dim 128
 
 
 def test_python_entry_points_and_error_behaviour():
@@ -112,16 +119,17 @@ def test_python_entry_points_and_error_behaviour():
 
 
 def test_head_dim_rule_matches_reference_assert():
-    """D % 16 == 0 and D <= 128 (FA2-triton.py:178) is checked before the compiled-kernel set."""
+    """D % 16 == 0 and D <= 128 (FA2-triton.py:178) is checked before the compiled-kernel set -- with the bound moved to 256
+    (forward only) for the wide-head kernel: every head_dim the reference accepts is accepted, none it accepts is rejected."""
     class FakeCuda(torch.Tensor):
         @property
         def is_cuda(self):
             return True
-    for D, msg in ((24, "D % 16"), (256, "D % 16"), (136, "D % 16")):
+    for D, msg in ((24, "D % 16"), (272, "D % 16"), (136, "D % 16"), (512, "D % 16")):
         t = torch.zeros(1, 1, 8, D).as_subclass(FakeCuda)
         with pytest.raises(fa.FlashAttnArgumentError, match=msg):
             fa.check_args(t, t, t)
-    for D in (16, 32, 48, 64, 80, 96, 112, 128):          # the reference's accepted head dims
+    for D in (16, 32, 48, 64, 80, 96, 112, 128, 144, 192, 256):   # the reference's accepted head dims, and the wide ones
         t = torch.zeros(1, 1, 8, D).as_subclass(FakeCuda)
         fa.check_args(t, t, t)
 
@@ -305,7 +313,7 @@ def test_concurrent_builds_compile_once_and_staleness_is_by_content(tmp_path):
     assert all(p.returncode == 0 for p in procs), errs
     assert log.read_text().count("call") == 1                    # one compile for four processes
     assert not _build.is_stale()
-    assert fa.load_library(_build.LIB_PATH).fa_version() == 130
+    assert fa.load_library(_build.LIB_PATH).fa_version() == 131
 
 
 def test_build_digest_covers_every_kernel_source():

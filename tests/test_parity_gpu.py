@@ -24,7 +24,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 def _lib_loaded_from_tree():
     lib = fa.load_library()
-    assert lib.fa_version() == 130
+    assert lib.fa_version() == 131
     return lib
 
 
