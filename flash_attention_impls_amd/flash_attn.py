@@ -169,6 +169,8 @@ def _kernel_ready(t: torch.Tensor) -> torch.Tensor:
     """Return t itself if the kernel can address it (unit head_dim stride, 16-byte aligned
     rows), otherwise a contiguous copy (the reference passes arbitrary strides to Triton,
     FA2-triton.py:190-193; the copy keeps that contract)."""
+    if t.is_contiguous() and t.data_ptr() % 16 == 0:     # (head_dim % 16 == 0: every row of a contiguous tensor is 16-byte aligned)
+        return t
     es = t.element_size()
     ok = (t.stride(3) == 1 and t.data_ptr() % 16 == 0
           and all((s * es) % 16 == 0 and s >= 0 for s in t.stride()[:3])
@@ -205,6 +207,28 @@ def check_args(q, k, v) -> None:
         raise FlashAttnArgumentError(f"head_dim must satisfy D % 16 == 0 and D <= {MAX_HEAD_DIM}; got {D}")
 
 
+class _on_device:
+    """The launch context of a tensor's device: makes it current only if it is not already (``torch.cuda.device`` costs a few
+    microseconds per call even then -- a third of the host time of a small launch) and hands out the raw current stream."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device: torch.device):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        return torch._C._cuda_getCurrentRawStream(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     """Launch the forward on kernel-ready tensors (head_dim 64 or 128).  Returns (o, lse or None)."""
     code = _dtype_code(q.dtype)
@@ -216,8 +240,7 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     if B * H * N == 0:
         return o, lse
     dsc = (ctypes.c_float * 3)(*descale) if descale is not None else None
-    with torch.cuda.device(q.device), _trace_range("FA2_FWD"):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _on_device(q.device) as stream, _trace_range("FA2_FWD"):
         lse_ptr = lse.data_ptr() if lse is not None else None
         if code == FA_DTYPE_FP8_E4M3:
             nbytes = lib.fa_fp8_workspace_bytes(B, H, max(N, Nk), D)
@@ -245,8 +268,7 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     dk = torch.empty((B, Hkv, Nk, D), dtype=o.dtype, device=o.device)
     dv = torch.empty_like(dk)
     do = _kernel_ready(do.to(q.dtype))
-    with torch.cuda.device(q.device), _trace_range("FA2_BWD"):
-        stream = torch.cuda.current_stream().cuda_stream
+    with _on_device(q.device) as stream, _trace_range("FA2_BWD"):
         nbytes = lib.fa_bwd_ex_workspace_bytes(B, H, Hkv, N, Nk, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
         rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
