@@ -27,6 +27,9 @@
 #ifndef FA_SGB_VARIANT
 #define FA_SGB_VARIANT 1
 #endif
+#ifndef FA_EARLY_EPILOGUE
+#define FA_EARLY_EPILOGUE 1
+#endif
 
 namespace fa {
 
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // K ring [kStages][TILE], then V ring
+    __shared__ __attribute__((aligned(16))) unsigned fa_flags16[2][8];        // per-wave fallback verdicts, by pass parity (outside the ring)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -717,13 +721,66 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     }  // !LEAN
     FA_PHASE(5);                // drain, staging-only tiles
 
+    float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
+    // ---- epilogue: combine the four lane groups' row sums, normalise, store O (and LSE)
+    auto epilogue = [&]() {
+    const int lane_e = lane_here();                // (fresh lane coordinates: see lane_here)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int li = lane_e & 15, lg = lane_e >> 4;
+        float l = l_part[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = (l > 0.f) ? p.out_scale / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
+        const int qrow = q0w + 16 * qt + li;
+        if (p.lse != nullptr && lg == 0 && qrow < S) {
+            // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)
+            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+        }
+        // lane (li,lg) holds O[qrow][16 dt + 4 lg + 0..3].  Pair head_dim tiles (dt, dt+1) with permlane16_swap so
+        // that each lane stores 16 contiguous bytes: even lg -> tile dt, columns 4 lg .. 4 lg + 7;
+        // odd lg -> tile dt+1, columns 4 (lg-1) .. 4 (lg-1) + 7.
+        elem_t* orow = oh + (long long)qrow * p.o_ss;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt += 2) {
+            const f32x4 oa = o_acc[dt][qt], ob = o_acc[dt + 1][qt];
+            unsigned a0 = T::pack2(oa[0] * inv, oa[1] * inv), a1 = T::pack2(oa[2] * inv, oa[3] * inv);
+            unsigned b0 = T::pack2(ob[0] * inv, ob[1] * inv), b1 = T::pack2(ob[2] * inv, ob[3] * inv);
+            // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second
+            auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            // even lg: {own a, (lg+1)'s a} ; odd lg: {(lg-1)'s b, own b}
+            u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+            const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+            if (qrow < S && col < p.dv) {
+                *reinterpret_cast<u32x4*>(orow + col) = outv;
+            }
+        }
+    }
+    };
     // ---- exact fallback (rare): plain per-tile online softmax with running max and rescale
     // A lane's row-sum share below kPLimit bounds every P it produced (all terms are positive); NaN fails the test.
-    float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     dma_wait<0>();                                 // no DMA may still be writing LDS past this point
-    // (flag words in the last V stage: the next pass's prologue does not write there, and its first later DMA sits
-    // behind a barrier)
+#if FA_EARLY_EPILOGUE
+    // A wave that has finished its tiles stores its output at once -- while the waves with more of the causal diagonal still
+    // compute -- instead of waiting for them first: the result is the final one unless some wave of the workgroup asks for
+    // the exact loop, which then recomputes and stores every row again.  Each wave posts its verdict in a flag word of its
+    // own (outside the ring: slower waves are still reading tiles) before the ONE barrier that also retires the ring.
+    bool redo;
+    {
+        const bool bad = !(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit);
+        const unsigned flags = (unsigned)(uintptr_t)(lds_char*)&fa_flags16[pass & 1][0];
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane_here() == 0) lds_write_b32(flags + 4 * wave, wave_bad ? 1u : 0u);
+        epilogue();
+        __syncthreads();
+        const u32x4 f0 = lds_read_b128(flags), f1 = lds_read_b128(flags + 16);
+        redo = __builtin_amdgcn_readfirstlane(f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0;
+    }
+    if (redo) {
+#else
     if (wg_any(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
+#endif
         constexpr int KO = 0, VO = VBASE;                     // two stages each: K at KO, V at VO
         const int lane = lane_here();                         // (fresh lane coordinates: see lane_here)
         const int li = lane & 15, lg = lane >> 4;
@@ -827,49 +884,20 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         }
         dma_wait<0>();
         __syncthreads();                       // every wave is done with the fallback's LDS stages
+#if FA_EARLY_EPILOGUE
+        epilogue();
+#endif
     }
 
-    FA_PHASE(6);                // fallback check (two barriers)
-    // ---- the next query block of a causal pair travels while this block's output is normalised and stored
+    FA_PHASE(6);                // fallback check
+    // ---- the next query block of a causal pair
     if (pass + 1 < n_pass) {
         issue_prologue();
         load_q(tq, lane_here());
     }
-
-    // ---- epilogue: combine the four lane groups' row sums, normalise, store O (and LSE)
-    const int lane_e = lane_here();                // (fresh lane coordinates: see lane_here)
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int li = lane_e & 15, lg = lane_e >> 4;
-        float l = l_part[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        const float inv = (l > 0.f) ? p.out_scale / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
-        const int qrow = q0w + 16 * qt + li;
-        if (p.lse != nullptr && lg == 0 && qrow < S) {
-            // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)
-            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
-        }
-        // lane (li,lg) holds O[qrow][16 dt + 4 lg + 0..3].  Pair head_dim tiles (dt, dt+1) with permlane16_swap so
-        // that each lane stores 16 contiguous bytes: even lg -> tile dt, columns 4 lg .. 4 lg + 7;
-        // odd lg -> tile dt+1, columns 4 (lg-1) .. 4 (lg-1) + 7.
-        elem_t* orow = oh + (long long)qrow * p.o_ss;
-#pragma unroll
-        for (int dt = 0; dt < DT; dt += 2) {
-            const f32x4 oa = o_acc[dt][qt], ob = o_acc[dt + 1][qt];
-            unsigned a0 = T::pack2(oa[0] * inv, oa[1] * inv), a1 = T::pack2(oa[2] * inv, oa[3] * inv);
-            unsigned b0 = T::pack2(ob[0] * inv, ob[1] * inv), b1 = T::pack2(ob[2] * inv, ob[3] * inv);
-            // v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second
-            auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-            auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-            // even lg: {own a, (lg+1)'s a} ; odd lg: {(lg-1)'s b, own b}
-            u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-            const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
-            if (qrow < S && col < p.dv) {
-                *reinterpret_cast<u32x4*>(orow + col) = outv;
-            }
-        }
-    }
+#if !FA_EARLY_EPILOGUE
+    epilogue();                 // (old order: output normalised and stored while the next block's first tiles travel)
+#endif
     FA_PHASE(7);                // epilogue (and the next pass's prologue issue)
   }  // pass
 #undef FA_PHASE
