@@ -287,10 +287,14 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 
     int stage_k = 0;                               // ring stage of tile j
     auto sync_and_stage = [&](int j) {
+#if !defined(FA8_ABL_NOBARRIER)                    // (timing-only ablation builds: wrong results)
         dma_wait<2 * CPT>();                       // everything but the previous iteration's DMA has landed ...
         __syncthreads();                           // ... and is published; the stages refilled below are no longer read
+#endif
+#if !defined(FA8_ABL_NODMA)
         dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
         dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+#endif
     };
     auto advance_k = [&]() {                       // K(j) -> K(j+1)
         const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
