@@ -319,6 +319,32 @@ def test_forced_exact_fallback(dt, amp, tile, causal):
     assert s > (70 if dt == "bf16" else 25)
 
 
+def test_forced_exact_fallback_in_one_pass_of_a_causal_pair():
+    """A launch large enough for paired query blocks (64 heads x 8 blocks: every workgroup runs the blocks (7 - t, t) in two
+    passes): the exact fallback is forced in the FIRST pass of a workgroup only (head 0), in the SECOND only (head 1), in both
+    (head 2) -- each pass posts its own verdict flags, stores early and redoes its block alone; the neighbours (head 3) and the
+    other pass must be untouched."""
+    B, H, S, D = 2, 32, 2048, 128
+    info = ctypes.c_int()
+    assert fa.load_library().fa_fwd_launch_info(B, H, S, D, 0, 1, ctypes.byref(info), None, None) == 0
+    assert info.value == B * H * 4                                         # 4 pairs per head: the paired schedule
+    q, k, v = rand_qkv(B, H, S, D, torch.bfloat16, seed=44)
+    q = q * 0.25
+    plain = fa.flash_attn(q, k, v, True)
+    k = k.clone()
+    k[0, 0, 1800] = (q[0, 0, 1900] * 160.0).to(torch.bfloat16)             # block 7 of head 0: first pass of workgroup (7, 0)
+    k[0, 1, 40] = (q[0, 1, 100] * 160.0).to(torch.bfloat16)                # block 0 of head 1: second pass of workgroup (7, 0)
+    k[0, 2, 1800] = (q[0, 2, 1900] * 160.0).to(torch.bfloat16)
+    k[0, 2, 40] = (q[0, 2, 100] * 160.0).to(torch.bfloat16)
+    o, lse = fa.flash_attn(q, k, v, True, return_lse=True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    ref, lse_ref = ref_f64(q[:1, :4], k[:1, :4], v[:1, :4], True)
+    assert_close(o[:1, :4], ref, TOL["bf16"], "fallback in one pass of a pair")
+    assert np.abs(lse[:1, :4].cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+    assert torch.equal(o[0, 3:], plain[0, 3:]) and torch.equal(o[1], plain[1])     # heads without a spike: bitwise as before
+    assert torch.equal(fa.flash_attn(q, k, v, True), o)
+
+
 def test_fallback_first_block_far_below_later_scores():
     """First key block scores ~ -120 nats below the rest for every row: every workgroup falls back."""
     B, H, S, D = 1, 2, 512, 64
