@@ -330,3 +330,16 @@ def test_build_digest_covers_every_kernel_source():
         with open(os.path.join(_build.CSRC, n)) as f:
             included |= set(re.findall(r'#include\s+"([^"]+)"', f.read()))
     assert {os.path.basename(i) for i in included} <= deps, included
+
+
+def test_graft_entry_checks_the_header_version_not_a_literal():
+    """build() compares the library with FA_VERSION of include/fa_mi355.h (a literal there once lagged a version bump and
+    would have failed the driver's build step); the in-tree library, the header and the Python loader agree."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    with open(os.path.join(root, "include", "fa_mi355.h")) as f:
+        header_version = int(re.search(r"#define\s+FA_VERSION\s+(\d+)", f.read()).group(1))
+    assert fa.load_library().fa_version() == header_version
+    with open(os.path.join(root, "__graft_entry__.py")) as f:
+        src = f.read()
+    assert "FA_VERSION" in src and not re.search(r"fa_version\(\)\s*==\s*\d", src)
