@@ -52,6 +52,10 @@ CASES = [
     ("bf16_d128_s513",      1, 1, 513, 128, "bf16", True,  7, 1.0, False),
     ("fp8_d128_nc",         1, 2, 256, 128, "fp8",  False, 8, 1.0, False),
     ("fp8_d128_causal",     1, 2, 256, 128, "fp8",  True,  9, 1.0, False),
+    # one dominant early key (an "attention sink": key 0 scores 8 nats above the rest for every query, the other keys together
+    # weigh about as much): pins where the fp8 kernel places each row's e4m3 window
+    ("fp8_d128_sink_nc",     1, 2, 384, 128, "fp8",  False, 10, 1.0, False),
+    ("fp8_d128_sink_causal", 1, 2, 384, 128, "fp8",  True,  11, 1.0, False),
 ]
 
 BWD_CASES = [
@@ -88,11 +92,19 @@ def to_storage(t, dtype):
 def main():
     ref = load_reference()
     os.makedirs(OUT, exist_ok=True)
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for (name, B, H, S, D, dtype, causal, seed, mul, run_kernel) in CASES:
+        if only and not any(o_ in name for o_ in only):
+            continue
         g = torch.Generator().manual_seed(seed)
         q = torch.randn(B, H, S, D, generator=g) * mul
         k = torch.randn(B, H, S, D, generator=g) * mul
         v = torch.randn(B, H, S, D, generator=g) * mul
+        if "sink" in name:
+            u = torch.randn(D, generator=g)
+            u *= math.sqrt(D) / u.norm()
+            q = q + u                                          # every query gains the common direction u ...
+            k[:, :, 0] = u * (8.0 / math.sqrt(D))              # ... and key 0 is u: its score is 8 nats (+- 0.7) for every query
         extra = {}
         if dtype == "fp8":
             # per-tensor scale amax/448, e4m3fn storage; the oracle output
@@ -279,6 +291,8 @@ if __name__ == "__main__":
         sys.exit("reference not present: golden vectors can only be generated in the build container")
     if "--bwd-only" not in sys.argv:
         main()
+    if any(a.startswith("--only=") for a in sys.argv):
+        sys.exit(0)
     main_bwd()
     main_gqa()
     main_kvlen()
