@@ -91,3 +91,57 @@ def test_forward_backward_random_extended_shapes(case):
         gotg = leaf.grad.float().cpu().numpy()
         assert gotg.shape == r.shape and np.isfinite(gotg).all(), (case, key)
         assert np.abs(gotg - r).max() <= TOL[dt] * max(1.0, np.abs(r).max()), (case, key)
+
+
+# the two forward-only paths of round 2: fp8 inputs on the fp8 kernel (head_dim 80 .. 128) with score patterns that move
+# each row's e4m3 window (a dominant early key, an outlier key anywhere, scaled logits), and the wide-head kernel (144 .. 256)
+fwd_only = st.tuples(st.sampled_from(["fp8", "wide"]), st.integers(1, 2), st.integers(1, 3), st.sampled_from([1, 2, 4]),
+                     st.integers(1, 700), st.integers(-200, 400), st.integers(0, 4), st.booleans(),
+                     st.sampled_from(["plain", "scaled", "sink", "outlier"]), st.integers(0, 2 ** 16))
+
+
+@settings(max_examples=50, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(fwd_only)
+def test_forward_random_shapes_fp8_and_wide_heads(case):
+    import math
+    from conftest import FP8_REL_FRO, FP8_TOL
+    path, B, Hkv, G, S, extra, dsel, causal, pattern, seed = case
+    Sk = max(1, S + extra)
+    H = Hkv * G
+    D = [80, 96, 112, 128, 128][dsel] if path == "fp8" else [144, 160, 192, 224, 256][dsel]
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, H, S, D, generator=g)
+    k = torch.randn(B, Hkv, Sk, D, generator=g)
+    v = torch.randn(B, Hkv, Sk, D, generator=g)
+    if pattern == "scaled":
+        q = q * 3.0
+    elif pattern == "sink":                              # key 0 (or a later one of the first tile) scores ~ 8 nats for every query
+        u = torch.randn(D, generator=g)
+        u = u * (math.sqrt(D) / u.norm())
+        q = q + u
+        k[:, :, seed % min(16, Sk)] = u * (8.0 / math.sqrt(D))
+    elif pattern == "outlier":
+        k[:, :, seed % Sk] = q[:, ::G, seed % S] * 4.0
+    if path == "fp8":
+        ds = tuple(float(t.abs().max()) / 448.0 for t in (q, k, v))
+        qd, kd, vd = [(t / s_).to(torch.float8_e4m3fn).cuda() for t, s_ in zip((q, k, v), ds)]
+        o, lse = fa.flash_attn(qd, kd, vd, causal, descale=ds, return_lse=True)
+        qn, kn, vn = [t.float().cpu().numpy().astype(np.float64) * s_ for t, s_ in zip((qd, kd, vd), ds)]
+    else:
+        qd, kd, vd = [t.to(torch.bfloat16).cuda() for t in (q, k, v)]
+        o, lse = fa.flash_attn(qd, kd, vd, causal, return_lse=True)
+        qn, kn, vn = [t.float().cpu().numpy() for t in (qd, kd, vd)]
+    ref, lse_ref = orc.naive_attention_f64(qn, np.repeat(kn, G, axis=1), np.repeat(vn, G, axis=1), causal=causal)
+    got = o.float().cpu().numpy()
+    assert np.isfinite(got).all(), case
+    scale = max(1.0, np.abs(ref).max())
+    if path == "fp8":
+        assert np.linalg.norm(got - ref) <= FP8_REL_FRO * max(np.linalg.norm(ref), 1e-9), case
+        assert np.abs(got - ref).max() <= FP8_TOL * scale, case
+    else:
+        assert np.abs(got - ref).max() <= TOL["bf16"] * scale, case
+    live = np.isfinite(lse_ref)
+    lg = lse.cpu().numpy()
+    assert np.array_equal(np.isfinite(lg), live), case
+    if live.any():
+        assert np.abs(lg[live] - lse_ref[live]).max() <= 2e-3 * max(1.0, np.abs(lse_ref[live]).max()), case
