@@ -69,6 +69,8 @@ def parse():
                     help="untimed back-to-back steps directly before the counted warm-up, by GPU time (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--rehearse-gather", action="store_true",
+                    help="run the gather timings in a gloo rehearsal too (exercises the code path on a 1-GPU box; the numbers mean nothing)")
     ap.add_argument("--gather-chunks", type=int, default=4, help="chunks of the overlapped compute || all-gather variant")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--dist-backend", default="auto", choices=["auto", "nccl", "gloo"],
@@ -304,8 +306,13 @@ def main():
     achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
 
     gather = None
-    if dist is not None and not args.no_gather and not rehearsal:
-        gather = time_gather(dist, fa, q, k, v, causal, descale, world, args.gather_chunks, barrier, dev)
+    if dist is not None and not args.no_gather and (not rehearsal or args.rehearse_gather):
+        # after the timed region and outside `value`: a failure here (a collective the backend lacks, memory) must not cost
+        # the run its bench line -- but it must be collective-safe, so every rank takes the same path and reports its error
+        try:
+            gather = time_gather(dist, fa, q, k, v, causal, descale, world, args.gather_chunks, barrier, dev)
+        except Exception as e:  # noqa: BLE001
+            gather = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         traffic, traffic_note = measured_traffic(args.workload + ("_fwdbwd" if fwdbwd else ""))
@@ -360,7 +367,7 @@ def time_gather(dist, fa, q, k, v, causal, descale, world, chunks, barrier, dev)
     of slice i on a second stream.  Both after the timed region; neither is part of `value`."""
     B = q.shape[0]
     o = fa.flash_attn(q, k, v, causal, descale=descale).detach()
-    full = torch.empty((world,) + tuple(o.shape), dtype=o.dtype, device=dev)
+    full = torch.empty((world * o.shape[0],) + tuple(o.shape[1:]), dtype=o.dtype, device=dev)   # ranks concatenated along the batch
     for _ in range(2):
         dist.all_gather_into_tensor(full, o)
     barrier()
@@ -386,7 +393,7 @@ def time_gather(dist, fa, q, k, v, causal, descale, world, chunks, barrier, dev)
     if chunks > 1 and B % chunks == 0:
         bc = B // chunks
         comm = torch.cuda.Stream(device=dev)
-        parts = [torch.empty((world, bc) + tuple(o.shape[1:]), dtype=o.dtype, device=dev) for _ in range(chunks)]
+        parts = [torch.empty((world * bc,) + tuple(o.shape[1:]), dtype=o.dtype, device=dev) for _ in range(chunks)]
 
         def overlapped():
             main = torch.cuda.current_stream()

@@ -65,7 +65,7 @@ def test_bench_gpus2_from_a_plain_shell():
     JSON line comes through.  On a one-GPU box the ranks fall back to the gloo rehearsal (all on cuda:0)."""
     env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--settle-ms", "30", "--workload", "cfg2", "--no-cpu-baseline"],
+                          "--settle-ms", "30", "--workload", "cfg2", "--no-cpu-baseline", "--rehearse-gather"],
                          cwd=ROOT, env=env_clean, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -73,3 +73,8 @@ def test_bench_gpus2_from_a_plain_shell():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
     assert out["step_ms_min"] <= out["step_ms_median"] <= out["step_ms_max"]
+    # the final-gather timings (blocking, compute-then-gather, chunked compute || gather) ran end to end -- over gloo here,
+    # so only that the code path works is checked, not its numbers
+    g = out["gather"]
+    assert "error" not in g, g
+    assert g["ms"] > 0 and g["compute_then_gather_ms"] > 0 and g["overlapped_total_ms"] > 0 and g["overlap_chunks"] >= 2
