@@ -30,6 +30,17 @@
 #ifndef FA_EARLY_EPILOGUE
 #define FA_EARLY_EPILOGUE 1
 #endif
+// FA_CONT_RING: the K/V ring keeps streaming across the two query blocks of a causal pair (see `cont` in the kernel)
+#ifndef FA_CONT_RING
+#define FA_CONT_RING 1
+#endif
+#ifndef FA_CONT_EARLY_Q
+#define FA_CONT_EARLY_Q 1
+#endif
+// FA_DMA_SOFF: in the unrolled steady loop the tile offset of a staging DMA rides in the instruction's scalar offset
+#ifndef FA_DMA_SOFF
+#define FA_DMA_SOFF 1
+#endif
 
 namespace fa {
 
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     u32x4 qf[2][QK8 ? 1 : KS]; // Q fragments [query tile][k-step] of the current pass (16-bit Q)
     u32x2 qf8[2][QK8 ? KS : 1];    // ... fp8 Q: eight bytes per lane and k-step
+    bool staged = false;           // the previous pass left this pass's first tiles in the ring, landed and published (cont)
 
   for (int pass = 0; pass < n_pass; ++pass) {
     const int qb = CAUSAL ? ((pass == 0) ? p.nqb - 1 - tq : tq) : tq;      // (unpaired: one pass, longest blocks first)
@@ -155,6 +167,13 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
     const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
+    // Continuous ring: the staging slots of a pass's last three iterations, which would fetch tiles past its diagonal,
+    // fetch the NEXT pass's first tiles instead -- K(0..2), V(0..1) of the same head, exactly what issue_prologue() stages --
+    // so the next query block starts without a prologue and without a wait.  Needs the next pass's tile 0 to fall on ring
+    // stage 0 (nt a multiple of the ring depth: always, when S_k - S is a multiple of 256).
+    const bool cont = FA_CONT_RING && CAUSAL && !LEAN && (pass + 1 < n_pass) && nt >= kStages && (nt & (kStages - 1)) == 0;
+    const int ntw = cont ? nt : 0x3fffffff;                           // tile index wrap of the staging DMAs
+    auto tk = [&](int t) { return t >= ntw ? t - ntw : t; };
 
     auto load_q = [&](int qblk, int lane_q) {     // (lane coordinates passed in: the call behind the main loop brings fresh ones)
         const int li = lane_q & 15, lg = lane_q >> 4;
@@ -213,15 +232,24 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         for (int i = 0; i < CPT; ++i)
             dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + stage_off + i * PIECE), (unsigned)j * v_tile_stride + g_voff[i]);
     };
-    // piece I of the K(j + 3), V(j + 2) staging that follows barrier j (K pieces first); stage_j = ring stage of tile j
-    auto dma_piece = [&] __device__ (auto i_c, int j, int stage_j) {
+    int stage_k = 0;                               // ring stage of tile j
+    // piece I of the K(j + 3), V(j + 2) staging that follows barrier j (K pieces first); ring stage of tile j: ST if >= 0 (the
+    // unrolled steady loop: its tiles all lie inside the buffer and before the wrap point, so the tile offset rides in the
+    // scalar-offset field and nothing but the LDS address is computed per piece), else stage_k (generic iterations: tile
+    // index wrapped, tile offset in the range-checked vector offset)
+    auto dma_piece = [&] __device__ (auto i_c, int j, auto st_c) {
         constexpr int I = decltype(i_c)::value;
-        if constexpr (I < CPTK)
-            dma16(rk_w, __builtin_amdgcn_readfirstlane(kpiece_base + ((stage_j + 3) & (kStages - 1)) * TILE + I * PIECE),
-                  (unsigned)(j + 3) * k_tile_stride + g_koff[I]);
-        else if constexpr (I < CPTK + CPT)
-            dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + ((stage_j + 2) & (kStages - 1)) * TILE + (I - CPTK) * PIECE),
-                  (unsigned)(j + 2) * v_tile_stride + g_voff[I - CPTK]);
+        constexpr int ST = decltype(st_c)::value;
+        const int stage_j = ST < 0 ? stage_k : ST;
+        if constexpr (I < CPTK) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(kpiece_base + ((stage_j + 3) & (kStages - 1)) * TILE + I * PIECE);
+            if constexpr (ST >= 0 && FA_DMA_SOFF) dma16s(rk_w, dst, g_koff[I], (unsigned)(j + 3) * k_tile_stride);
+            else dma16(rk_w, dst, (unsigned)(ST >= 0 ? j + 3 : tk(j + 3)) * k_tile_stride + g_koff[I]);
+        } else if constexpr (I < CPTK + CPT) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(piece_base + VBASE + ((stage_j + 2) & (kStages - 1)) * TILE + (I - CPTK) * PIECE);
+            if constexpr (ST >= 0 && FA_DMA_SOFF) dma16s(rv_w, dst, g_voff[I - CPTK], (unsigned)(j + 2) * v_tile_stride);
+            else dma16(rv_w, dst, (unsigned)(ST >= 0 ? j + 2 : tk(j + 2)) * v_tile_stride + g_voff[I - CPTK]);
+        }
     };
 
     // ---- LDS read addresses (they carry the ring-stage offset of the tile currently being read)
@@ -371,7 +399,6 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     // One pipeline block n (HALF = n & 1): MFMA  PV(n-2) | S(n);  VALU softmax(n-1);  four fenced regions of
     // 8 MFMAs + one softmax slice + one fragment-group read each (see fa_fwd_kernel.hpp for the protocol).
-    int stage_k = 0;                               // ring stage of tile j
     // DMA = true (odd blocks only): the four staging pieces that follow this iteration's barrier are issued one per
     // region boundary instead of back to back behind the barrier
     auto block_d = [&] __device__ (auto dma_c, auto half_c, auto do_s_c, auto do_sm_c, auto do_pv_c, auto mask_c, auto first_c, auto st_c, int n, int dk, int dv) {
@@ -431,15 +458,15 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             if constexpr (DMA) {
 #if FA_DMA_SPREAD == 2          // two pieces in front of each S region
                 if constexpr (R == 1 || R == 3) {
-                    dma_piece(IC<R - 1>{}, n >> 1, ST < 0 ? stage_k : ST);
-                    dma_piece(IC<R>{}, n >> 1, ST < 0 ? stage_k : ST);
+                    dma_piece(IC<R - 1>{}, n >> 1, st_c);
+                    dma_piece(IC<R>{}, n >> 1, st_c);
                 }
 #elif FA_DMA_SPREAD == 1        // one piece per region
-                dma_piece(r_c, n >> 1, ST < 0 ? stage_k : ST);
+                dma_piece(r_c, n >> 1, st_c);
 #else                           // two pieces in front of each PV region (measured: the three placements are within noise)
                 if constexpr (R == 0 || R == 2) {
-                    dma_piece(IC<R>{}, n >> 1, ST < 0 ? stage_k : ST);
-                    dma_piece(IC<R + 1>{}, n >> 1, ST < 0 ? stage_k : ST);
+                    dma_piece(IC<R>{}, n >> 1, st_c);
+                    dma_piece(IC<R + 1>{}, n >> 1, st_c);
                 }
 #endif
             }
@@ -509,11 +536,13 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     FA_PHASE(10);               // (diagnostic) offsets, addresses, accumulator init
     if (pass == 0) issue_prologue();
     FA_PHASE(11);               // (diagnostic) prologue DMAs issued
+    if (!staged) {
     if constexpr (LEAN) dma_wait<2 * (CPTK + CPT)>();
     // this wave's pieces of K(0) (and, older, its Q fragments) have landed; V(0) may still be in flight: its first reader is
     // the fragment prefetch at the end of block 1, behind iteration 0's own wait and barrier, which cover it
     else dma_wait<2 * CPTK + 2 * CPT>();
     __syncthreads();            // ... and every wave's are visible
+    }
     FA_PHASE(0);                // pass start -> first tiles visible (what remains of it: the wait for Q / K(0) and the barrier)
 
     int dk = 0, dv = 0;                            // address deltas used by the odd block of iteration j
@@ -529,9 +558,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         __syncthreads();                           // ... and is published; last iteration's reads are done
 #endif
 #if !defined(FA_ABL_NODMA)
-        dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
+        dma_k(tk(j + 3), ((stage_k + 3) & (kStages - 1)) * TILE);
         if constexpr (LEAN) dma_v(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
-        else dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+        else dma_v(tk(j + 2), ((stage_k + 2) & (kStages - 1)) * TILE);
 #endif
     };
     auto end_iter = [&]() { stage_k = (stage_k + 1) & (kStages - 1); };
@@ -641,8 +670,11 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         FA_PHASE(1);            // fill iteration
         const int ja = min(jm, NT);
         // steady state, no masking, four tiles per trip: the ring stage of every LDS access is an immediate
-        // (no address arithmetic in the loop).  j = 1 on entry, so the stages run 1, 2, 3, 0.
-        if (j + 4 <= ja) {
+        // (no address arithmetic in the loop).  j = 1 on entry, so the stages run 1, 2, 3, 0.  A trip that starts at j stages
+        // tiles up to K(j + 6): the unrolled form only runs while those are whole tiles of this pass (inside the buffer, before
+        // the wrap point of a continuous ring); the last three iterations of a pass are always generic ones.
+        const int ju = min(ja, min(ntw, Sk / kBN) - 3);
+        if (j + 4 <= ju) {
             const int sk0 = stage_k * TILE, sv0 = ((stage_k + 3) & 3) * TILE;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) ka[ks] -= sk0;           // stage-0 bases
@@ -658,7 +690,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
                 FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<ST>{}, NN + 1, 0, 0); \
                 const unsigned long long t3 = stamp_now(); \
                 st_e += t1 - t0; st_w += t2 - t1; st_o += t3 - t2; st_n += 1; } while (0)
-            for (; j + 4 <= ja; j += 4) {
+            for (; j + 4 <= ju; j += 4) {
                 FA_STAMPED_TILE(1, j, 2 * j);
                 FA_STAMPED_TILE(2, j + 1, 2 * j + 2);
                 FA_STAMPED_TILE(3, j + 2, 2 * j + 4);
@@ -667,7 +699,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 #undef FA_STAMPED_TILE
             st_last = stamp_now();
 #else
-            for (; j + 4 <= ja; j += 4) {
+            for (; j + 4 <= ju; j += 4) {
                 block(half0_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j, 0, 0);
                 FA_SYNC_STAGE_C(IC<1>{}, j);
                 FA_ODD_BLOCK(half1_t{}, Y{}, Y{}, Y{}, N{}, N{}, IC<1>{}, 2 * j + 1, 0, 0);
@@ -704,12 +736,17 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             end_iter();
         }
         FA_PHASE(4);            // masked tiles
+        // this wave's last S product is issued: the Q fragments of the next query block can take the registers now and travel
+        // under the drain, the staging-only tiles and the normalisation
+        if (FA_CONT_EARLY_Q && cont) load_q(tq, lane_here());
         begin_iter(j);                             // iteration NT (pipeline drain)
         block(half0_t{}, N{}, Y{}, Y{}, Y{}, N{}, IC<-1>{}, 2 * j, 0, 0);
         if (j < nt) sync_and_stage(j);
         block(half1_t{}, N{}, N{}, Y{}, N{}, N{}, IC<-1>{}, 2 * j + 1, dk, dv);
         end_iter();
         ++j;
+    } else if (FA_CONT_EARLY_Q && cont) {
+        load_q(tq, lane_here());
     }
 #undef FA_SYNC_STAGE
 #undef FA_SYNC_STAGE_C
@@ -723,24 +760,25 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     // ---- epilogue: combine the four lane groups' row sums, normalise, store O (and LSE)
-    auto epilogue = [&]() {
+    // (two halves with `mid()` between them: everything that needs no memory -- row sums, 1/l, packing, lane exchange -- first,
+    //  then the caller's wait for its staging DMAs and the next Q fragments, then the stores, which stay in flight across the
+    //  barrier that follows)
+    auto epilogue = [&] __device__ (auto mid) {
     const int lane_e = lane_here();                // (fresh lane coordinates: see lane_here)
+    const int li = lane_e & 15, lg = lane_e >> 4;
+    u32x4 outv[2][DT / 2];
+    float lsev[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        const int li = lane_e & 15, lg = lane_e >> 4;
         float l = l_part[qt];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         const float inv = (l > 0.f) ? p.out_scale / l : 0.f;        // flash_attn_cutlass.cu:446-452 guard
-        const int qrow = q0w + 16 * qt + li;
-        if (p.lse != nullptr && lg == 0 && qrow < S) {
-            // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)
-            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
-        }
+        // lse = m*scale + ln(l) = (m_c + log2(l)) * ln(2)
+        lsev[qt] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
         // lane (li,lg) holds O[qrow][16 dt + 4 lg + 0..3].  Pair head_dim tiles (dt, dt+1) with permlane16_swap so
         // that each lane stores 16 contiguous bytes: even lg -> tile dt, columns 4 lg .. 4 lg + 7;
         // odd lg -> tile dt+1, columns 4 (lg-1) .. 4 (lg-1) + 7.
-        elem_t* orow = oh + (long long)qrow * p.o_ss;
 #pragma unroll
         for (int dt = 0; dt < DT; dt += 2) {
             const f32x4 oa = o_acc[dt][qt], ob = o_acc[dt + 1][qt];
@@ -750,35 +788,60 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
             auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
             // even lg: {own a, (lg+1)'s a} ; odd lg: {(lg-1)'s b, own b}
-            u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
+            outv[qt][dt / 2] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+    }
+    mid();
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qrow = q0w + 16 * qt + li;
+        if (p.lse != nullptr && lg == 0 && qrow < S) p.lse[((long long)b * p.H + h) * S + qrow] = lsev[qt];
+        elem_t* orow = oh + (long long)qrow * p.o_ss;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt += 2) {
             const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
             if (qrow < S && col < p.dv) {
-                *reinterpret_cast<u32x4*>(orow + col) = outv;
+                *reinterpret_cast<u32x4*>(orow + col) = outv[qt][dt / 2];
             }
         }
     }
     };
+    auto no_mid = [] __device__ () {};
     // ---- exact fallback (rare): plain per-tile online softmax with running max and rescale
     // A lane's row-sum share below kPLimit bounds every P it produced (all terms are positive); NaN fails the test.
-    dma_wait<0>();                                 // no DMA may still be writing LDS past this point
 #if FA_EARLY_EPILOGUE
     // A wave that has finished its tiles stores its output at once -- while the waves with more of the causal diagonal still
     // compute -- instead of waiting for them first: the result is the final one unless some wave of the workgroup asks for
     // the exact loop, which then recomputes and stores every row again.  Each wave posts its verdict in a flag word of its
-    // own (outside the ring: slower waves are still reading tiles) before the ONE barrier that also retires the ring.
+    // own (outside the ring: slower waves are still reading tiles) before the ONE barrier that also retires the ring -- and,
+    // on a continuous ring, publishes the next query block's first tiles.
     bool redo;
     {
         const bool bad = !(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit);
         const unsigned flags = (unsigned)(uintptr_t)(lds_char*)&fa_flags16[pass & 1][0];
         const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane_here() == 0) lds_write_b32(flags + 4 * wave, wave_bad ? 1u : 0u);
-        epilogue();
+        epilogue([&] __device__ () {
+            dma_wait<0>();                         // no DMA may still be writing LDS past this point; the next Q fragments are in
+            if (FA_CONT_EARLY_Q && cont) {         // (consumed here, so that hipcc places its own wait for them here -- where it
+#pragma unroll                                     //  costs nothing -- and not behind the stores at their first use)
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int ks = 0; ks < (QK8 ? 1 : KS); ++ks) asm volatile("" :: "v"(qf[qt][ks]));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                    for (int ks = 0; ks < (QK8 ? KS : 1); ++ks) asm volatile("" :: "v"(qf8[qt][ks]));
+            }
+        });
         __syncthreads();
         const u32x4 f0 = lds_read_b128(flags), f1 = lds_read_b128(flags + 16);
         redo = __builtin_amdgcn_readfirstlane(f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0;
     }
     if (redo) {
+        if (FA_CONT_EARLY_Q && cont) load_q(qb, lane_here());  // (the registers already hold the next block's fragments)
 #else
+    dma_wait<0>();                                 // no DMA may still be writing LDS past this point
     if (wg_any(!(l_part[0] < T::kPLimit && l_part[1] < T::kPLimit), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
 #endif
         constexpr int KO = 0, VO = VBASE;                     // two stages each: K at KO, V at VO
@@ -885,18 +948,27 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         dma_wait<0>();
         __syncthreads();                       // every wave is done with the fallback's LDS stages
 #if FA_EARLY_EPILOGUE
-        epilogue();
+        epilogue(no_mid);
 #endif
     }
 
     FA_PHASE(6);                // fallback check
     // ---- the next query block of a causal pair
+    staged = false;
     if (pass + 1 < n_pass) {
-        issue_prologue();
-        load_q(tq, lane_here());
+#if FA_EARLY_EPILOGUE
+        if (cont && !redo) {                       // its first tiles and Q fragments are in place (continuous ring)
+            staged = true;
+            if (!FA_CONT_EARLY_Q) load_q(tq, lane_here());
+        } else
+#endif
+        {
+            issue_prologue();
+            load_q(tq, lane_here());
+        }
     }
 #if !FA_EARLY_EPILOGUE
-    epilogue();                 // (old order: output normalised and stored while the next block's first tiles travel)
+    epilogue(no_mid);           // (old order: output normalised and stored while the next block's first tiles travel)
 #endif
     FA_PHASE(7);                // epilogue (and the next pass's prologue issue)
   }  // pass

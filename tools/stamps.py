@@ -24,6 +24,13 @@ q, k, v = (torch.randn(a.B, a.H, a.S, 128, device="cuda").to(torch.bfloat16) for
 for _ in range(30):
     fa.flash_attn(q, k, v, bool(a.causal))
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    fa.flash_attn(q, k, v, bool(a.causal))
+e1.record()
+torch.cuda.synchronize()
+wall_us = e0.elapsed_time(e1) / 20 * 1e3
 n_wg = min(8192, a.B * a.H * ((a.S + 255) // 256) // (2 if a.causal else 1))
 buf = np.zeros((n_wg, 8, 24), dtype=np.uint64)
 rc = lib.fa_debug_read_stamps(buf.ctypes.data, buf.nbytes)
@@ -53,3 +60,20 @@ ph = f[:, :, 8:20].copy()
 ph[:, :, 2] += f[:, :, 0] + f[:, :, 1] + f[:, :, 2]        # the unrolled loop's cycles are kept in the segment sums
 for i, nme in enumerate(names):
     print(f"  {nme:36s} {ph[:, :, i][ok].mean():9.0f}   [{ph[:, :4, i].mean():9.0f} | {ph[:, 4:, i].mean():9.0f}]")
+
+# dispatch gap: wall time of one launch against the in-kernel lifetimes of the workgroups a CU runs one after the other
+n_cu = 256
+rounds = -(-n_wg // n_cu)
+life_us = (f[:, :, 5].max(axis=1) / 100.0)           # s_memrealtime ticks are 10 ns
+print(f"launch wall {wall_us:.1f} us; {rounds} rounds of workgroups per CU; mean workgroup lifetime {life_us.mean():.1f} us "
+      f"(x rounds = {life_us.mean() * n_wg / n_cu:.1f} us): outside any workgroup {wall_us - life_us.mean() * n_wg / n_cu:.1f} us per launch "
+      f"= {(wall_us - life_us.mean() * n_wg / n_cu) / max(1, n_wg / n_cu) * 1e3 * tot.mean() / rt.mean() / 10:.0f} cycles per workgroup slot")
+# by dispatch round (blockIdx / 256): does the start-up phase cost more when every CU starts a workgroup at once?
+print("by dispatch round (blockIdx // 256): whole workgroup | pass start -> first tiles visible | Q loads issued | prologue DMAs issued   [cycles, mean over waves]")
+for r in range(rounds):
+    sl = slice(r * n_cu, min(n_wg, (r + 1) * n_cu))
+    print(f"  round {r}: {f[sl, :, 4].mean():9.0f} | {ph[sl, :, 0].mean():8.0f} | {ph[sl, :, 9].mean():8.0f} | {ph[sl, :, 11].mean():8.0f}")
+# per wave (causal: wave w < 4 owns row block w, wave w >= 4 row block 11 - w): the phases around the end of a pass
+print("per wave: pass start | fill | leftover | masked | drain+staging-only | fallback check (own stores, the barrier) | epilogue")
+for w in range(8):
+    print(f"  wave {w}: " + " | ".join(f"{ph[:, w, i].mean():8.0f}" for i in (0, 1, 3, 4, 5, 6, 7)))
