@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_NAME = "libfa_mi355.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 
-SOURCES = [os.path.join(CSRC, "fa_capi.hip"), os.path.join(CSRC, "fa_bwd_capi.hip")]
+SOURCES = [os.path.join(CSRC, "fa_capi.hip"), os.path.join(CSRC, "fa_bwd_capi.hip"), os.path.join(CSRC, "fa_diag.hip")]
 # every file under csrc/ is a dependency (kernel headers are included from the two sources above): a header added later is
 # picked up without touching this list, and the digest below covers exactly what the compiler reads
 DEPS = SOURCES + sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC)

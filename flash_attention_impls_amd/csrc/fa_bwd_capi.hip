@@ -86,7 +86,7 @@ int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int
 
 // Parts a key/value head's group of G query heads is split into for the dK/dV kernel.  One workgroup per (key block,
 // key/value head) streams all G query heads; with few key/value heads and a small batch (multi-query attention above
-// all) that is too few, too unequal workgroups for 256 CUs.  Splitting the group over `parts` workgroups multiplies the
+// all) that is too few, too unequal workgroups for the 256 CUs.  Splitting the group over `parts` workgroups multiplies the
 // grid; each part writes fp32 partial sums and fa_bwd_reduce_kernel adds them up (fixed order: still deterministic).
 // Measured (cfg3-like shapes with 1 ... 8 key/value heads, S = 4096 ... 16384): under the causal mask, where workgroups
 // are of very unequal length, splitting pays up to about 2048 workgroups; without it only until the chip is full.
@@ -95,7 +95,8 @@ int run_prep(const void* o, const void* d_o, const float* lse, float* stats, int
 void dkdv_parts(int B, int H_kv, int G, int S_q, int S_k, bool causal, int& gparts, int& qparts)
 {
     gparts = qparts = 1;
-    const long long want = causal ? 2048 : 512;
+    const long long cus = fa_capi::device_cus();     // (256 on a whole MI355X; the workspace query and the launch see the same device)
+    const long long want = causal ? 8 * cus : 2 * cus;
     const long long wgs = (long long)B * H_kv * ((S_k + 127) / 128);
     const long long tiles = (S_q + fa::kBN - 1) / fa::kBN;
     if (wgs >= want) return;                         // enough workgroups for the dispatcher to balance
@@ -104,8 +105,8 @@ void dkdv_parts(int B, int H_kv, int G, int S_q, int S_k, bool causal, int& gpar
         if (G % d == 0) { gparts = d; if (wgs * d >= want) break; }
     // the query range is split only where there are fewer workgroups than CUs: its partial sums are as large as dK and
     // dV themselves per part (measured: with 512 or more workgroups the extra traffic costs more than the balance gains)
-    if (wgs * gparts >= 256) return;
-    const long long more = (512 + wgs * gparts - 1) / (wgs * gparts);
+    if (wgs * gparts >= cus) return;
+    const long long more = (2 * cus + wgs * gparts - 1) / (wgs * gparts);
     qparts = (int)std::max(1ll, std::min(std::min(more, tiles / 4), 8ll));
 }
 
@@ -281,7 +282,7 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
 
     // under the causal mask a dQ workgroup takes a pair of query blocks (see fa_bwd_kernel.hpp), unless single blocks are
     // expected to finish earlier (fa_capi::causal_unpaired)
-    pq.unpaired = (causal != 0 && fa_capi::causal_unpaired((long long)B * H, pq.nxb)) ? 1 : 0;
+    pq.unpaired = (causal != 0 && fa_capi::causal_unpaired((long long)B * H, pq.nxb, fa_capi::device_cus())) ? 1 : 0;
     pq.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);
     pk.hsplit = fa_capi::head_split((long long)pk.bh, pk.nxb);
     const int grid_q = bwd_grid((long long)B * H, (causal != 0 && !pq.unpaired) ? (pq.nxb + 1) / 2 : pq.nxb);

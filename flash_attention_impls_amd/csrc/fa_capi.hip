@@ -148,7 +148,7 @@ int launch_c(const fa::FwdParams& p, int grid, bool causal, int bm, hipStream_t 
             // head_dim 64: the 16x16 kernel fits two workgroups per CU (128 VGPRs, 64 KiB of LDS: +11-12 % at cfg3's
             // batch and sequence); launches that do not fill the chip twice (cfg2: 128 workgroups) are latency-bound and
             // 5 % faster on the 32x32 kernel
-            if (grid > 512)
+            if (grid > 2 * fa_capi::device_cus())
                 return causal ? launch16<T, true, D>(p, grid, s) : launch16<T, false, D>(p, grid, s);
             return causal ? launch<T, D, true>(p, grid, s) : launch<T, D, false>(p, grid, s);
         }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
 bool unpaired_for(int B, int H, int S, bool causal, int bm = fa::kBM)
 {
     const long long nqb = (S + bm - 1) / bm;
-    return causal && fa_capi::causal_unpaired((long long)B * H, nqb);
+    return causal && fa_capi::causal_unpaired((long long)B * H, nqb, fa_capi::device_cus());
 }
 
 int grid_for(int B, int H, int S, bool causal, int bm = fa::kBM)
@@ -221,7 +221,7 @@ int grid_wide(int B, int H, int S, int* hsplit)
 }
 
 // Query rows per workgroup of a 16-bit launch: 256 (8 waves), or 128 (4 waves, head_dim <= 64 only) when the 256-row grid
-// would leave a quarter or more of the 256 CUs without a workgroup -- small launches are latency-bound, and a CU that holds
+// would leave a quarter or more of the CUs (256 on a whole MI355X) without a workgroup -- small launches are latency-bound, and a CU that holds
 // no workgroup contributes nothing (cfg2: 128 workgroups of 256 rows -> 256 of 128 rows)
 int rows_per_wg(int B, int H, int S, int D, bool causal)
 {
@@ -231,7 +231,7 @@ int rows_per_wg(int B, int H, int S, int D, bool causal)
 #else
     if (D > 64 || S <= 128) return fa::kBM;
     const int g = grid_for(B, H, S, causal);
-    return (g > 0 && g <= 192) ? 128 : fa::kBM;
+    return (g > 0 && 4 * g <= 3 * fa_capi::device_cus()) ? 128 : fa::kBM;
 #endif
 }
 

@@ -28,6 +28,24 @@ inline bool set_strides(const int64_t* s, int H, int S, int D, long long& sb, lo
     return sb >= 0 && sh >= 0 && ss >= D;
 }
 
+// Compute units of the current device (hipDeviceProp_t::multiProcessorCount, read once per device; 256 if the query fails):
+// the launch heuristics below count rounds of workgroups against it instead of assuming a whole MI355X (SPX mode, 256 CUs),
+// so a partitioned device (DPX / QPX / CPX: 128 / 64 / 32 CUs) is scheduled by its own size.  The XCD count stays 8 in the
+// kernels' workgroup decode (blockIdx % 8): on a partition with fewer XCDs that is only a permutation of the blocks.
+inline int device_cus()
+{
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> cus[kMaxDevices];          // zero-initialised; 0 = not read yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    int n = cus[dev].load(std::memory_order_acquire);
+    if (n > 0) return n;
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus[dev].store(n, std::memory_order_release);
+    return n;
+}
+
 // Grid mapping shared by all kernels (wg_decode in fa_fwd_kernel.hpp): blockIdx % 8 = XCD, all blocks of a (batch, head)
 // slice on one XCD.  A head count that is small and not a multiple of 8 would leave XCDs idle (4 heads: half the chip):
 // each head then becomes 2, 4 or 8 virtual heads that share its blocks, so that the virtual heads fill all 8 XCDs evenly.
@@ -51,16 +69,16 @@ inline long long grid_blocks(long long heads, long long per_head, int hsplit)
 }
 
 // Causal launches: pair the blocks of a head (nb-1-t, t) into workgroups of equal work, or launch them one by one, longest
-// first?  Pairs are perfectly balanced but quantised: G workgroups on 256 CUs take ceil(G / 256) rounds of nb + 1 block
+// first?  Pairs are perfectly balanced but quantised: G workgroups on `cus` CUs (256 on a whole MI355X) take ceil(G / cus) rounds of nb + 1 block
 // units.  Single blocks take about max(nb, total work / 256) with some slack for the greedy order.  Returns true when the
 // single-block launch is expected to finish first (small grids, and grids whose last round of pairs would be mostly empty).
-inline bool causal_unpaired(long long heads, long long nb)
+inline bool causal_unpaired(long long heads, long long nb, int cus = 256)
 {
     if (nb <= 1) return false;
     const long long pairs = heads * ((nb + 1) / 2);
-    const double t_pair = (double)((pairs + 255) / 256) * (double)(nb + 1);
+    const double t_pair = (double)((pairs + cus - 1) / cus) * (double)(nb + 1);
     const double work = (double)heads * (double)nb * (double)(nb + 1) / 2.0;
-    const double t_single = std::max((double)nb, 1.2 * work / 256.0);
+    const double t_single = std::max((double)nb, 1.2 * work / (double)cus);
     return t_single < 0.85 * t_pair;                 // (measured: at equal estimates the pairs win, the greedy order is no LPT)
 }
 

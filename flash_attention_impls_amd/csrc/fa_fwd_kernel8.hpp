@@ -15,7 +15,7 @@
 //     ds_read_b64_tr_b8 per head_dim tile, each gathering 8 key rows (key tiles 2 m and 2 m + 1) x 16 columns
 //     (tools/probes/ds_read_tr8_probe.cpp: lane 2 q + p of a 16-lane group supplies the address of row q, lane i receives
 //     column i of the 8 rows);
-//   * P in e4m3: P = exp2(score - reference + b) with the reference fixed from the row's first 16 keys and b (0 .. 8) placing
+//   * P in e4m3: P = exp2(score - reference + b) with the reference fixed from the row's first 128-key block and b (0 .. 8) placing
 //     e4m3's 2^-9 .. 448 window by how far that reference stands out of its own key tile (kGapFree8 below: ordinary rows get
 //     b ~ 0.5 and typical P in 2^-7 .. 2^4, a row led by a dominant early key gets b = 8); a P beyond e4m3's
 //     range converts to NaN, which poisons the row's sum on the matrix pipe and sends the
@@ -33,8 +33,8 @@ namespace fa {
 
 constexpr int kBN8 = 128;                      // keys per tile (= per block) of the fp8 kernel
 // Where a row's P sit in e4m3 (2^-9 .. 448, full precision from 2^-6 up).  The softmax reference of a row is the maximum mx of
-// its first 16 keys and is shown to e4m3 as P(mx) = 2^b, b = clamp(gap - kGapFree8, 0, kPRefTop8) with gap = mx - (mean of those
-// 16 scores), in binades: the top of the window stands 8.86 + kGapFree8 binades above the MEAN of the first key tile (7.5 sigma on
+// its first 128 keys (round 2: 16) and is shown to e4m3 as P(mx) = 2^b, b = clamp(gap - kGapFree8, 0, kPRefTop8) with gap = mx -
+// (mean of those scores), in binades (the numbers that follow were measured with the 16-key sample): the top of the window stands 8.86 + kGapFree8 binades above the MEAN of the first key tile (7.5 sigma on
 // N(0,1) data; measured on config 5's shard: kGapFree8 = 1 costs 2.6 % in workgroups sent to the exact loop, 2 costs 0.4 %, and
 // a max-anchored b = 3 sends 14 % of the workgroups there: -25 %), but never lower than just above mx itself -- a dominant early key (an "attention sink") then sits at the top of e4m3
 // and the many small terms under it, which together can weigh as much as the sink, stay in full precision down to 14.8 binades
@@ -46,6 +46,7 @@ constexpr int kBN8 = 128;                      // keys per tile (= per block) of
 constexpr float kGapFree8 = FA8_GAP_FREE;
 constexpr float kPRefTop8 = 8.0f;
 constexpr float kGapFloor8 = 12.0f;            // a score further than this below mx counts as mx - 12 in the mean (one very low key must not move the window)
+constexpr float kSumFloor8 = 0.92f;            // WANT_LSE: rounded row sum below this share of the exact one -> exact fallback (underflowed weight)
 constexpr float kPLimit8 = 1e30f;              // a rounded row sum not below this (i.e. NaN: some P left e4m3's range) -> exact fallback
 
 // 16-byte-chunk swizzles of the 128-byte rows (two rows per 256-byte bank row)
@@ -240,35 +241,51 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, pf[par][qt][kt], false), true);
         }
     };
-    // the first key tile of a row's first block fixes its softmax reference and the place of its e4m3 window (kGapFree8 above)
-    auto sm_set_reference = [&] __device__ (auto mask_c, int key0) {
-        constexpr bool MASK = decltype(mask_c)::value;
+    // The row's FIRST 128-KEY BLOCK fixes its softmax reference and the place of its e4m3 window (kGapFree8 above), in a
+    // pre-pass of its own before the pipelined loop: the eight score tiles of the block are formed once more (16 MFMAs and
+    // ~100 VALU per wave and pass: < 1 % of a pass), only their row maximum, clamped sum and count are kept.  (Until round 3
+    // the first 16 keys alone decided: a row whose first 16 keys were ALL comparably dominant, with a broad tail 7 nats below
+    // them, got b = 0 and lost the tail -- a fifth of its weight at S = 4096 -- to e4m3's underflow, silently.  With 128 keys
+    // the tail is in the sample and opens the window downwards; what remains out of reach is a row whose first 128 keys are
+    // all dominant: the WANT_LSE variant then notices that the rounded and the exact row sums disagree and takes the exact
+    // loop, the variant without LSE has no exact sums to compare with -- stated in include/fa_mi355.h.)
+    auto set_reference_from_first_block = [&] __device__ (bool masked) {
+        float mx[2] = {-INFINITY, -INFINITY}, sm[2] = {0.f, 0.f}, cn[2] = {0.f, 0.f};
+        const float span = kGapFloor8 * __builtin_amdgcn_rcpf(c);
+        auto tile_stats = [&] __device__ (auto mask_c, int kt) {
+            constexpr bool MASK = decltype(mask_c)::value;
+            const u32x4 w0 = lds_read_b128(ka[0] + kt * 16 * ROWB), w1 = lds_read_b128(ka[1] + kt * 16 * ROWB);
+            const i32x8 kx = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const f32x4 sx = mfma8(kx, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                const int lim = limq[qt] - 16 * kt;                       // (keys past the causal limit / the last key: not counted)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool in = true;
+                    if constexpr (MASK) in = (e <= lim);
+                    mx[qt] = in ? fmaxf(mx[qt], sx[e]) : mx[qt];
+                    // a score far below the (running) maximum counts as maximum - 12 binades: one very low key must not move the window
+                    sm[qt] += in ? fmaxf(sx[e], mx[qt] - span) : 0.f;
+                    cn[qt] += in ? 1.f : 0.f;
+                }
+            }
+        };
+        if (masked) {                      // (the first 128 rows of a causal head, a key length under 128: rare -- a rolled loop)
+#pragma unroll 1
+            for (int kt = 0; kt < 8; ++kt) tile_stats(std::true_type{}, kt);
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) tile_stats(std::false_type{}, kt);
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = -INFINITY, cnt = 0.f;
-            const int lim = limq[qt] - key0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bool in = true;
-                if constexpr (MASK) in = (e <= lim);
-                mx = in ? fmaxf(mx, s_acc[0][qt][e]) : mx;
-                cnt += in ? 1.f : 0.f;
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));   cnt += __shfl_xor(cnt, 16);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));   cnt += __shfl_xor(cnt, 32);
-            const float floor_s = mx - kGapFloor8 * __builtin_amdgcn_rcpf(c);
-            float sum = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bool in = true;
-                if constexpr (MASK) in = (e <= lim);
-                sum += in ? fmaxf(s_acc[0][qt][e], floor_s) : 0.f;
-            }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float gap = (mx - sum * __builtin_amdgcn_rcpf(fmaxf(cnt, 1.f))) * c;          // 0 .. 12 binades
+            float m = mx[qt], u = sm[qt], n = cn[qt];
+            m = fmaxf(m, __shfl_xor(m, 16));   u += __shfl_xor(u, 16);   n += __shfl_xor(n, 16);
+            m = fmaxf(m, __shfl_xor(m, 32));   u += __shfl_xor(u, 32);   n += __shfl_xor(n, 32);
+            const float gap = (m - u * __builtin_amdgcn_rcpf(fmaxf(n, 1.f))) * c;               // 0 .. 12 binades
             const float b = fminf(fmaxf(gap - kGapFree8, 0.f), kPRefTop8);                      // (a NaN gap gives 0)
-            m_c[qt] = (mx == -INFINITY) ? 0.f : __builtin_fmaf(mx, c, -b);
+            m_c[qt] = (m == -INFINITY) ? 0.f : __builtin_fmaf(m, c, -b);
         }
     };
 
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             if constexpr (R == 0) {
                 if constexpr (SL0) sm_slice(mask_c, IC<PAR ^ 1>{}, IC<7>{}, key0 - kBN8);
             } else if constexpr (SL) {
-                if constexpr (FIRST && R == 1) sm_set_reference(mask_c, key0);
+                (void)FIRST;
                 sm_slice(mask_c, IC<PAR>{}, IC<R - 1>{}, key0);
             }
 #if !defined(FA8_NO_SGB)
@@ -391,9 +408,10 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 7) : 0x7fffffff, Sk >> 7);
     int j = 0;
     if (NT > 0) {
+        set_reference_from_first_block(0 >= (min(CAUSAL ? (max(0, q0w + coff) >> 7) : 0x7fffffff, Sk >> 7)));   // (block 0 needs the mask)
         read_k(IC<0>{}, IC<0>{});
         read_k(IC<1>{}, IC<1>{});
-        // block 0 (pipeline fill): scores and slices only; its first key tile fixes the reference
+        // block 0 (pipeline fill): scores and slices only (the reference is fixed: pre-pass above)
         block8(IC<0>{}, Y{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, true, 0);
         swap_pf();
         stage_k = (stage_k + 1) & (kStages - 1);
@@ -429,7 +447,20 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     // tools/probes/cvt_fp8_probe.cpp) and poisons the row's rounded sum on the matrix pipe -- no per-score bookkeeping.
     float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     dma_wait<0>();
-    if (wg_any(!(l_acc[0][0] < kPLimit8 && l_acc[1][0] < kPLimit8), lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
+    bool bad_row = !(l_acc[0][0] < kPLimit8 && l_acc[1][0] < kPLimit8);
+    if constexpr (WANT_LSE) {
+        // second trigger, where the exact sums exist anyway: the rounded P of a row add up to clearly less than the exact P,
+        // i.e. a share of the row's weight sat below the window and was rounded to zero (e4m3's own rounding moves a sum by at
+        // most 2^-4, and in both directions; a dominant term rounded down alone can make 6.25 %)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float le = l_part[qt];
+            le += __shfl_xor(le, 16);
+            le += __shfl_xor(le, 32);
+            bad_row = bad_row || (l_acc[qt][0] < kSumFloor8 * le);
+        }
+    }
+    if (wg_any(bad_row, lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
         constexpr int KO = 0, VO = VBASE;
         const int lane_f = lane_here();
         const int li = lane_f & 15, lg = lane_f >> 4;

@@ -73,15 +73,25 @@ def gather_output(o_local: torch.Tensor, units: int, group=None) -> torch.Tensor
     return torch.cat(parts, dim=0)
 
 
+def _out_dtype(q: torch.Tensor) -> torch.dtype:
+    """Element type of O for inputs of q's type: fp8 inputs give a bf16 output (fa_fwd_fp8), 16-bit inputs their own, fp32
+    inputs fp32 (the operator computes those in fp16 and converts back, FA2-triton.py:241-244)."""
+    return torch.bfloat16 if q.dtype == torch.float8_e4m3fn else q.dtype
+
+
 def flash_attn_sharded(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
                        attn_fn: Callable | None = None, group=None, gather: bool = True,
-                       rank: int | None = None, world: int | None = None):
+                       rank: int | None = None, world: int | None = None, always_collective: bool = False,
+                       **attn_kwargs):
     """Every rank holds the full inputs (or at least its own units); each computes its contiguous slice of the
     B * H_kv units and, if ``gather``, all ranks receive the full (B, H, S, D) output.
 
     ``attn_fn`` defaults to the HIP ``flash_attn``; CPU tests inject an oracle here to exercise the sharding/gather
     logic over gloo.  ``rank`` / ``world`` default to the process group's; passing them (with ``gather=False``) computes
     any rank's shard in a single process, which is how the GPU tests check the split against the unsharded launch.
+    ``attn_kwargs`` (``descale=...`` for fp8 inputs, ``softmax_scale=...``) are passed through to ``attn_fn``.
+    ``always_collective``: run the all-gather even at world size 1 (a one-rank RCCL communicator is valid: this is how a
+    one-GPU box executes the collective path for real).
     """
     if attn_fn is None:
         from .flash_attn import flash_attn as attn_fn
@@ -96,9 +106,11 @@ def flash_attn_sharded(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal
     G = H // Hkv
     ql = local_shard(q, rank, world, G)
     kl, vl = local_shard(k, rank, world), local_shard(v, rank, world)
-    o_local = attn_fn(ql, kl, vl, causal) if ql.shape[0] > 0 else ql.new_empty(ql.shape)
+    # a rank without units still takes part in the gather: its (empty) shard must have the OUTPUT's element type -- for fp8
+    # inputs that is bf16, not q's -- or the ranks' buffers of all_gather_into_tensor disagree in type and size
+    o_local = attn_fn(ql, kl, vl, causal, **attn_kwargs) if ql.shape[0] > 0 else ql.new_empty(ql.shape, dtype=_out_dtype(q))
     if not gather:
         return o_local
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_initialized()):
         return o_local.reshape(B, H, S, D)
     return gather_output(o_local, B * Hkv, group).reshape(B, H, S, D)

@@ -115,6 +115,11 @@ def _declare(lib):
     lib.fa_fwd_launch_info.restype = c.c_int
     lib.fa_fwd_launch_info.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int,
                                        c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    if hasattr(lib, "fa_diag_mfma_loop"):      # (diagnostics, FA_VERSION >= 132; A/B arms built from older sources lack them)
+        lib.fa_device_cus.restype = c.c_int
+        lib.fa_device_cus.argtypes = []
+        lib.fa_diag_mfma_loop.restype = c.c_int
+        lib.fa_diag_mfma_loop.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.POINTER(c.c_double), c.c_void_p]
     return lib
 
 

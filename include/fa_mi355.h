@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 131          /* 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
+#define FA_VERSION 132          /* 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -112,6 +112,21 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
                const int64_t* v_strides, const int64_t* o_strides,
                int causal, float softmax_scale, const float* descale,
                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Diagnostics (no reference counterpart; the reference's protocol asks for "% of peak", code/README.md:41-43, and this is
+ * the measured ceiling that fraction can be read against):
+ *   fa_device_cus()     compute units of the current device as the launch heuristics see them (256 on a whole MI355X).
+ *   fa_diag_mfma_loop() enqueues ONE launch of a kernel that does nothing but back-to-back dense MFMAs of the given element
+ *                       type (FA_DTYPE_BF16 / FA_DTYPE_FP16: v_mfma_f32_16x16x32; FA_DTYPE_FP8_E4M3:
+ *                       v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales) on every CU, two waves per SIMD, 64 x iters
+ *                       MFMAs per wave, operand fragments taken from `operands` (>= 64 KiB of device memory holding data of
+ *                       that type: the matrix cores' power draw depends on it) and kept in registers.  *flops_out = FLOPs of
+ *                       the launch; `sink` = one device float (never written in practice).  Timed by the caller
+ *                       (bench.py: `roofline.attainable`).
+ */
+int fa_device_cus(void);
+int fa_diag_mfma_loop(int dtype, int iters, const void* operands, float* sink, double* flops_out, void* stream);
 
 /*
  * Contiguous [B,H,N,D] convenience entry with the reference dispatcher's argument order

@@ -56,6 +56,14 @@ CASES = [
     # weigh about as much): pins where the fp8 kernel places each row's e4m3 window
     ("fp8_d128_sink_nc",     1, 2, 384, 128, "fp8",  False, 10, 1.0, False),
     ("fp8_d128_sink_causal", 1, 2, 384, 128, "fp8",  True,  11, 1.0, False),
+    # round 3: the least-pinned regimes of the fp8 path.
+    # An outlier INSIDE the keys that fix a row's reference: key 5 is 6 x query 1000, so its score against the other queries is
+    # N(0, 6^2) nats -- anything from far below to tens of binades above the rest (the (5, 1000) case that failed in round 2).
+    ("fp8_d128_outlier5_nc",     1, 2, 1024, 128, "fp8", False, 12, 1.0, False),
+    # Twelve comparably dominant keys at the very start (7.0 .. 7.4 nats above the rest for every query) over a broad tail that
+    # still carries ~10 % of each row's weight: a window placed from the first 16 keys alone (b = 0) rounds the whole tail to zero.
+    ("fp8_d128_multisink_nc",     1, 1, 1024, 128, "fp8", False, 13, 1.0, False),
+    ("fp8_d128_multisink_causal", 1, 1, 1024, 128, "fp8", True,  14, 1.0, False),
 ]
 
 BWD_CASES = [
@@ -100,7 +108,15 @@ def main():
         q = torch.randn(B, H, S, D, generator=g) * mul
         k = torch.randn(B, H, S, D, generator=g) * mul
         v = torch.randn(B, H, S, D, generator=g) * mul
-        if "sink" in name:
+        if "outlier5" in name:
+            k[:, :, 5] = q[:, :, 1000] * 6.0
+        elif "multisink" in name:
+            u = torch.randn(D, generator=g)
+            u *= math.sqrt(D) / u.norm()
+            q = q + u
+            for i in range(12):
+                k[:, :, i] = u * ((7.0 + 0.4 * i / 11.0) / math.sqrt(D))
+        elif "sink" in name:
             u = torch.randn(D, generator=g)
             u *= math.sqrt(D) / u.norm()
             q = q + u                                          # every query gains the common direction u ...

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import FP8_REL_FRO
+from conftest import FP8_REL_FRO, FP8_ROW_MAX, FP8_TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -120,10 +120,11 @@ def _ref64(q, k, v, ds, causal):
 
 
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("key,query", [(700, 900), (130, 200), (40, 1000)])
+@pytest.mark.parametrize("key,query", [(700, 900), (130, 200), (40, 1000), (5, 1000)])
 def test_fp8_forced_exact_fallback(causal, key, query):
-    """A P beyond e4m3's range (here: one key, outside the row's first 16, whose score lies tens of binades above the reference
-    fixed from them) turns into NaN in the conversion, poisons that row's sum on the matrix pipe and sends the workgroup to the
+    """A P beyond e4m3's range (here: one key whose score lies tens of binades above the reference of most rows -- outside the
+    row's first block, or, (5, 1000) and (40, 1000), inside it, where it IS the reference of the rows it dominates and far
+    below it for others) turns into NaN in the conversion, poisons that row's sum on the matrix pipe and sends the workgroup to the
     exact running-maximum loop: the output must come out as accurate as on ordinary data, for every row of the workgroup."""
     q, k, v, ds = _fp8_case(1, 2, 2, 1024, 1024, 128, seed=key, spike=(key, query, 6.0))
     o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
@@ -187,7 +188,71 @@ def test_fp8_one_outlier_key_in_the_first_tile():
     assert np.isfinite(o).all()
     assert np.linalg.norm(o - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
     rows = np.linalg.norm(o - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), 1e-3)
-    assert np.quantile(rows, 0.99) <= 2 * FP8_REL_FRO and rows.max() <= 4 * FP8_REL_FRO
+    assert np.quantile(rows, 0.99) <= 2 * FP8_REL_FRO and rows.max() <= FP8_ROW_MAX
+    # element-wise bound on the rows the outlier does not dominate (its softmax weight under a half)
+    s = _f64_attention(q, k, v, ds)[1]
+    w5 = np.exp(s[..., 5] - (np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)))
+    plain = w5 < 0.5
+    assert plain.mean() > 0.3
+    assert np.abs(o - ref)[plain].max() <= FP8_TOL * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("want_lse", [True, False])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("n_dom", [4, 12, 16, 40])
+def test_fp8_many_dominant_first_keys(n_dom, causal, want_lse):
+    """several comparably dominant keys at the very start (7.0 .. 7.4 nats above the rest for every query) over a
+    broad tail ~10 binades below them that still carries 10 - 50 % of each row's weight at S = 4096.  A window placed from the
+    first 16 keys alone sees no gap (b = 0) and rounds the whole tail to zero; the first-block sample (128 keys) contains the
+    tail and opens the window downwards.  Both kernel variants (with and without the exact row sums of the LSE)."""
+    Bn, Hh, Sn, Dh = 1, 2, 4096, 128
+    g = torch.Generator().manual_seed(100 + n_dom)
+    u = torch.randn(Dh, generator=g)
+    u *= math.sqrt(Dh) / u.norm()
+    qf = torch.randn(Bn, Hh, Sn, Dh, generator=g) + u
+    kf, vf = (torch.randn(Bn, Hh, Sn, Dh, generator=g) for _ in range(2))
+    for i in range(n_dom):
+        kf[:, :, i] = u * ((7.0 + 0.4 * i / max(1, n_dom - 1)) / math.sqrt(Dh))
+    ds = tuple(float(t.abs().max()) / 448.0 for t in (qf, kf, vf))
+    q, k, v = [(t / s_).to(torch.float8_e4m3fn).cuda() for t, s_ in zip((qf, kf, vf), ds)]
+    if want_lse:
+        o, lse = fa.flash_attn(q, k, v, causal, descale=ds, return_lse=True)
+    else:
+        o = fa.flash_attn(q, k, v, causal, descale=ds)
+    ref, s = _f64_attention(q, k, v, ds, causal)
+    lse_ref = np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)
+    w_dom = np.exp(s[..., :n_dom] - lse_ref[..., None]).sum(-1)
+    late = slice(512, None)                                          # (causal: rows that see a tail at all)
+    assert 0.3 < np.median(w_dom[..., late]) < 0.95                  # neither the dominant keys nor the tail is negligible
+    of = o.double().cpu().numpy()
+    assert np.isfinite(of).all()
+    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    rows = np.linalg.norm(of - ref, axis=-1) / np.maximum(np.linalg.norm(ref, axis=-1), 1e-3)
+    assert np.quantile(rows, 0.99) <= 2 * FP8_REL_FRO and rows.max() <= FP8_ROW_MAX
+    if want_lse:
+        assert np.abs(lse.double().cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+def test_fp8_a_whole_first_block_of_dominant_keys_is_caught_where_the_exact_sums_exist():
+    """The case no finite sample covers: ALL 128 keys of a row's first block dominant (7 nats), the tail after them.  The
+    sample shows no gap, the window stays high and the tail underflows.  The variant that forms the exact row sums (an LSE is
+    asked for) sees the rounded sum fall short of the exact one and takes the exact loop: result within the bound.  The
+    variant without them cannot notice -- the limitation stated in include/fa_mi355.h -- and is only required to stay finite."""
+    Bn, Hh, Sn, Dh = 1, 1, 4096, 128
+    g = torch.Generator().manual_seed(128)
+    u = torch.randn(Dh, generator=g)
+    u *= math.sqrt(Dh) / u.norm()
+    qf = torch.randn(Bn, Hh, Sn, Dh, generator=g) + u
+    kf, vf = (torch.randn(Bn, Hh, Sn, Dh, generator=g) for _ in range(2))
+    kf[:, :, :128] = u * (7.0 / math.sqrt(Dh)) + 0.02 * kf[:, :, :128]
+    ds = tuple(float(t.abs().max()) / 448.0 for t in (qf, kf, vf))
+    q, k, v = [(t / s_).to(torch.float8_e4m3fn).cuda() for t, s_ in zip((qf, kf, vf), ds)]
+    ref, s = _f64_attention(q, k, v, ds)
+    o, lse = fa.flash_attn(q, k, v, False, descale=ds, return_lse=True)
+    of = o.double().cpu().numpy()
+    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+    o2 = fa.flash_attn(q, k, v, False, descale=ds).double().cpu().numpy()
+    assert np.isfinite(o2).all()
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 2, 128, 128, 128), (2, 3, 3, 333, 333, 128), (1, 4, 2, 777, 777, 128), (1, 2, 2, 1, 1, 128),

@@ -54,27 +54,86 @@ def _run(cmd, timeout=600):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_fp8_shards_with_fewer_units_than_ranks():
+    """fp8 inputs give a bf16 output: a rank without units must return an empty bf16 shard (q's type would make the ranks'
+    all-gather buffers disagree), and the per-tensor scales reach the kernel through the sharded entry."""
+    B, H, S, D = 1, 3, 256, 128
+    g = torch.Generator().manual_seed(5)
+    f32 = [torch.randn(B, H, S, D, generator=g) for _ in range(3)]
+    dsc = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q, k, v = [(t / s_).to(torch.float8_e4m3fn).cuda() for t, s_ in zip(f32, dsc)]
+    ref = fa.flash_attn(q, k, v, False, descale=dsc)
+    parts = [flash_attn_sharded(q, k, v, False, gather=False, rank=r, world=8, descale=dsc) for r in range(8)]
+    assert [p.shape[0] for p in parts] == [1, 1, 1, 0, 0, 0, 0, 0]
+    assert all(p.dtype == torch.bfloat16 for p in parts)
+    assert torch.equal(torch.cat(parts, dim=0).reshape(B, H, S, D), ref)
+    assert not torch.equal(ref, fa.flash_attn(q, k, v, False))          # (the scales matter)
+
+
 def test_two_rank_gloo_rehearsal_on_one_gpu():
     res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_rehearsal_worker.py")])
+                "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_rehearsal_worker.py")])
     assert res.returncode == 0 and "DIST_REHEARSAL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
 def test_bench_gpus2_from_a_plain_shell():
-    """`python bench.py --gpus 2` with no launcher: bench.py starts its ranks itself (before touching the GPU) and rank 0's
-    JSON line comes through.  On a one-GPU box the ranks fall back to the gloo rehearsal (all on cuda:0)."""
+    """`python bench.py --gpus 2 --dist-backend gloo` with no launcher: bench.py starts its ranks itself (before touching the
+    GPU) and rank 0's JSON line comes through, marked as a rehearsal and without a `value` (all ranks share cuda:0)."""
     env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--settle-ms", "30", "--workload", "cfg2", "--no-cpu-baseline", "--rehearse-gather"],
+                          "--settle-ms", "30", "--workload", "cfg2", "--no-cpu-baseline", "--rehearse-gather",
+                          "--dist-backend", "gloo"],
                          cwd=ROOT, env=env_clean, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["rehearsal"] is True and out["value"] is None and out["rehearsal_value"] > 0     # cannot be mistaken for a measurement
     assert out["step_ms_min"] <= out["step_ms_median"] <= out["step_ms_max"]
     # the final-gather timings (blocking, compute-then-gather, chunked compute || gather) ran end to end -- over gloo here,
     # so only that the code path works is checked, not its numbers
     g = out["gather"]
     assert "error" not in g, g
     assert g["ms"] > 0 and g["compute_then_gather_ms"] > 0 and g["overlapped_total_ms"] > 0 and g["overlap_chunks"] >= 2
+
+
+def test_bench_more_ranks_than_gpus_is_an_error_not_a_silent_rehearsal():
+    """Default backend (auto = nccl): `--gpus 2` on a box with one GPU must fail, not print a normal-looking line."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has two GPUs")
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--settle-ms", "10", "--workload", "cfg2", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env_clean, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert "fewer GPUs than ranks" in res.stderr or "GPU(s) on this box" in res.stderr, res.stderr[-1500:]
+
+
+def test_rccl_path_at_world_size_one():
+    """The RCCL code path for real, on one GPU (a one-rank communicator is valid): bench.py under torch.distributed.run with
+    the nccl backend -- init_process_group(device_id=...), barriers, all_gather_into_tensor on device tensors, the
+    comm-stream overlap with record_stream -- and dist.flash_attn_sharded's all-gather.  What an 8-GPU node runs first."""
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                "--settle-ms", "30", "--workload", "cfg2", "--no-cpu-baseline", "--no-attainable", "--no-power",
+                "--dist-backend", "nccl", "--force-dist"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "rehearsal" not in out
+    g = out["gather"]
+    assert "error" not in g, g
+    assert g["ms"] > 0 and g["compute_then_gather_ms"] > 0 and g["overlapped_total_ms"] > 0
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_rehearsal_worker.py"), "--backend", "nccl"])
+    assert res.returncode == 0 and "DIST_REHEARSAL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]

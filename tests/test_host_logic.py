@@ -4,6 +4,7 @@ import os
 import re
 
 import pytest
+from conftest import header_version
 import torch
 
 import flash_attention_impls_amd as fa
@@ -33,7 +34,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
             "fa_fwd_launch_info", "fa_fwd_fp8", "fa_fp8_workspace_bytes"} <= set(syms)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/ but not exported"
-    assert lib.fa_version() == 131
+    assert lib.fa_version() == header_version()
     assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
 
 
@@ -313,7 +314,7 @@ def test_concurrent_builds_compile_once_and_staleness_is_by_content(tmp_path):
     assert all(p.returncode == 0 for p in procs), errs
     assert log.read_text().count("call") == 1                    # one compile for four processes
     assert not _build.is_stale()
-    assert fa.load_library(_build.LIB_PATH).fa_version() == 131
+    assert fa.load_library(_build.LIB_PATH).fa_version() == header_version()
 
 
 def test_build_digest_covers_every_kernel_source():

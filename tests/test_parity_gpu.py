@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOL, c_oracle_fwd, golden_names, golden_torch, load_golden
+from conftest import TOL, c_oracle_fwd, golden_names, golden_torch, load_golden, header_version
 from oracle import attn_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -24,7 +24,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
 
 def _lib_loaded_from_tree():
     lib = fa.load_library()
-    assert lib.fa_version() == 131
+    assert lib.fa_version() == header_version()
     return lib
 
 

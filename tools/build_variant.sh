@@ -7,4 +7,4 @@ src=${SRC:-$root}
 csrc=$src/flash_attention_impls_amd/csrc
 mkdir -p $root/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Wno-unused-result "$@" \
-    -o $root/build/lib$name.so $csrc/fa_capi.hip $csrc/fa_bwd_capi.hip && echo built $root/build/lib$name.so
+    -o $root/build/lib$name.so $csrc/fa_capi.hip $csrc/fa_bwd_capi.hip $csrc/fa_diag.hip && echo built $root/build/lib$name.so
