@@ -146,6 +146,14 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
     int head, tq;
     if (!wg_decode(blockIdx.x, p.bh, wg_per_head, p.hsplit, head, tq)) return;
+#if defined(FA_STAGGER)
+    // experiment: the workgroups of the first dispatch round start FA_STAGGER x 64 cycles apart (8 steps by slot), so that
+    // the equal-length workgroups that follow on each CU do not run their prologues (an HBM burst) all at the same moment
+    if (blockIdx.x < 256) {
+        const int st = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(FA_STAGGER);
+    }
+#endif
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;                         // query rows
