@@ -35,7 +35,7 @@ int main(int argc, char** argv)
     const int dtype = bf16 ? FA_DTYPE_BF16 : FA_DTYPE_FP16;
     printf("Flash Attention Performance Test (MI355X, libfa_mi355 %d)\n", fa_version());
     printf("B=%d, H=%d, N=%d, d=%d, runs=%d, causal=%d, dtype=%s\n", B, H, N, d, runs, causal, bf16 ? "bf16" : "fp16");
-    if (!fa_supported(dtype, d)) { fprintf(stderr, "head_dim %d has no compiled kernel (64, 128)\n", d); return 1; }
+    if (!fa_supported(dtype, d)) { fprintf(stderr, "head_dim %d is not supported (a multiple of 16 from 16 to 256)\n", d); return 1; }
 
     const size_t n = (size_t)B * H * N * d;
     std::vector<uint16_t> hq(n), hk(n), hv(n), ho(n);

@@ -35,6 +35,10 @@
 #pragma once
 #include "fa_fwd_kernel.hpp"
 
+#ifndef FA_BWD_HALF_PRIO
+#define FA_BWD_HALF_PRIO 0
+#endif
+
 namespace fa {
 
 struct BwdParams {
@@ -512,6 +516,9 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), MODE == 0 ? 2 : 1) void fa_
         setup_addresses();
         if constexpr (!PIPE) {
             // two waves per SIMD: the hardware interleaves one wave's matrix steps with its partner's softmax
+#if FA_BWD_HALF_PRIO
+            const int late_half = (NW == 8 && wave >= 4) ? 1 : 0;
+#endif
             auto sync_and_issue0 = [&](int j, int dst_stage) {
                 dma_wait<OPS>();                      // this wave's pieces of tile j have landed ...
                 __syncthreads();                      // ... every wave's are visible, and tile j-1 is no longer read
@@ -529,10 +536,19 @@ __global__ __launch_bounds__(64 * bwd_waves<MODE>(), MODE == 0 ? 2 : 1) void fa_
                 constexpr int ST = decltype(st_c)::value;
                 sync_and_issue0(j, (ST + 2) % NS);
                 const int b0 = 2 * j, b1 = 2 * j + 1;
+#if FA_BWD_HALF_PRIO
+                // behind the barrier the two waves of a SIMD start the same block together and the older one wins every
+                // arbitration, then waits at the next barrier: priority for the younger half in the first block of a tile
+                // evens the two out (forward: fa_fwd_kernel8.hpp, profiles/r3_ab_runs.txt)
+                setprio_if<1>(late_half);
+#endif
                 if (b0 >= blk_begin_w && b0 < blk_end_w) {
                     if (needs_mask(b0)) whole_block(std::true_type{}, IC<ST>{}, IC<0>{}, b0 * 32);
                     else whole_block(std::false_type{}, IC<ST>{}, IC<0>{}, b0 * 32);
                 }
+#if FA_BWD_HALF_PRIO
+                setprio_if<0>(late_half);
+#endif
                 if (b1 >= blk_begin_w && b1 < blk_end_w) {
                     if (needs_mask(b1)) whole_block(std::true_type{}, IC<ST>{}, IC<1>{}, b1 * 32);
                     else whole_block(std::false_type{}, IC<ST>{}, IC<1>{}, b1 * 32);

@@ -253,6 +253,14 @@ __device__ __forceinline__ void asm_mfma_bf16_acc(f32x16& d, u32x4 a, u32x4 b) {
     asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
 }
 
+// s_setprio PRIO executed by the waves with `late` != 0 only, without control flow the compiler can see (a branch of its own
+// inside the statement: a C++ `if` at a region boundary of a pipelined loop splits the scheduling region)
+template <int PRIO> __device__ __forceinline__ void setprio_if(int late) {
+    int tmp;        // (the flag travels in a vector register: under scalar-register pressure hipcc parks uniform values there anyway, and an "s" input it has parked does not assemble)
+    asm volatile("v_readfirstlane_b32 %0, %1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lfa_prio_%=\n\ts_setprio %2\n.Lfa_prio_%=:"
+                 : "=&s"(tmp) : "v"(late), "n"(PRIO) : "scc");
+}
+
 template <int V> using IC = std::integral_constant<int, V>;
 
 // This lane's index (0..63), produced in place by an opaque instruction pair.  Nothing derived from it can be hoisted

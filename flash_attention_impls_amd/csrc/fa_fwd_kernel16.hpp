@@ -40,6 +40,9 @@
 // FA_PP: "ping-pong" main loop at head_dim 128 (see the PP branch of the kernel): the two waves of a SIMD alternate a
 // matrix-only phase with a load / softmax phase, one barrier per phase.  Experiment; results are
 // bitwise those of the default loop.
+#ifndef FA_HALF_PRIO
+#define FA_HALF_PRIO 1
+#endif
 #ifndef FA_PP
 #define FA_PP 0
 #endif
@@ -259,6 +262,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         for (int i = 0; i < CPT; ++i)
             dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + stage_off + i * PIECE), (unsigned)j * v_tile_stride + g_voff[i]);
     };
+#if FA_HALF_PRIO
+    const int late_half = (wave >= 4) ? 1 : 0;
+#endif
     int stage_k = 0;                               // ring stage of tile j
     // piece I of the K(j + 3), V(j + 2) staging that follows barrier j (K pieces first); ring stage of tile j: ST if >= 0 (the
     // unrolled steady loop: its tiles all lie inside the buffer and before the wrap point, so the tile offset rides in the
@@ -500,6 +506,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         };
         // ---- region 0: PV, head_dim tiles 0..3 | softmax slice (kt 0, qt 0)
         __builtin_amdgcn_sched_barrier(0);
+#if FA_HALF_PRIO
+        // (the tile's barrier sits in front of the odd block: the younger wave of a SIMD gets priority there, see fa_fwd_kernel8.hpp)
+        if constexpr (DO_S && DO_SM && DO_PV) setprio_if<(HALF == 1 ? 1 : 0)>(late_half);
+#endif
         spread(IC<0>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DO_PV) {
@@ -953,6 +963,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         end_iter();
     }
     }  // !LEAN
+#if FA_HALF_PRIO
+    setprio_if<0>(late_half);   // (the last steady block of a pass is an odd one: back to the common priority)
+#endif
     FA_PHASE(5);                // drain, staging-only tiles
 
     float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};

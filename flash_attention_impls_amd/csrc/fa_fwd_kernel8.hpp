@@ -44,6 +44,9 @@ constexpr int kBN8 = 128;                      // keys per tile (= per block) of
 #define FA8_GAP_FREE 2.0f
 #endif
 constexpr float kGapFree8 = FA8_GAP_FREE;
+#ifndef FA8_HALF_PRIO
+#define FA8_HALF_PRIO 1
+#endif
 constexpr float kPRefTop8 = 8.0f;
 constexpr float kGapFloor8 = 12.0f;            // a score further than this below mx counts as mx - 12 in the mean (one very low key must not move the window)
 constexpr float kSumFloor8 = 0.92f;            // WANT_LSE: rounded row sum below this share of the exact one -> exact fallback (underflowed weight)
@@ -84,6 +87,19 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // K ring [kStages][TILE], then V ring
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#if defined(FA_STAMP)
+    // diagnostic build only (tools/stamps.py --dtype fp8): cycle sums per wave, as in fa_fwd_kernel16.hpp -- (a) a steady-state
+    // 128-key block split at its barrier: regions 0..3 | the counted wait + barrier + the four staging DMA pieces | regions 4..7;
+    // (b) the phases of a pass.  g_fa_stamp and stamp_now() are those of fa_fwd_kernel16.hpp.
+    unsigned long long st_e = 0, st_w = 0, st_o = 0, st_n = 0;
+    const unsigned long long st_t0 = stamp_now();
+    unsigned long long st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0) :: "memory");
+    unsigned long long st_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = st_t0, st_a = 0, st_b = 0;
+#define FA8_PHASE(K) do { const unsigned long long t_ = stamp_now(); st_ph[K] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define FA8_PHASE(K) do {} while (0)
+#endif
 
     const bool paired = CAUSAL && !p.unpaired;
     const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
@@ -138,7 +154,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             }
         }
     };
+    FA8_PHASE(8);               // (diagnostic) entry: parameters, workgroup decode, descriptors
     if (pass == 0) load_q(qb, lane);
+    FA8_PHASE(9);               // (diagnostic) Q loads issued
 
     // ---- K/V staging by LDS-DMA (1-KiB pieces = 8 rows; swizzle on the per-lane source address)
     unsigned g_koff[CPT], g_voff[CPT];
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     // all dominant: the WANT_LSE variant then notices that the rounded and the exact row sums disagree and takes the exact
     // loop, the variant without LSE has no exact sums to compare with -- stated in include/fa_mi355.h.)
     auto set_reference_from_first_block = [&] __device__ (bool masked) {
-        float mx[2] = {-INFINITY, -INFINITY}, sm[2] = {0.f, 0.f}, cn[2] = {0.f, 0.f};
+        float mx[2] = {-INFINITY, -INFINITY}, sm[2] = {0.f, 0.f}, sm2[2] = {0.f, 0.f}, cn[2] = {0.f, 0.f};
         const float span = kGapFloor8 * __builtin_amdgcn_rcpf(c);
         auto tile_stats = [&] __device__ (auto mask_c, int kt) {
             constexpr bool MASK = decltype(mask_c)::value;
@@ -259,15 +277,22 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const f32x4 sx = mfma8(kx, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-                const int lim = limq[qt] - 16 * kt;                       // (keys past the causal limit / the last key: not counted)
+                if constexpr (MASK) {
+                    const int lim = limq[qt] - 16 * kt;                   // (keys past the causal limit / the last key: not counted)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bool in = true;
-                    if constexpr (MASK) in = (e <= lim);
-                    mx[qt] = in ? fmaxf(mx[qt], sx[e]) : mx[qt];
-                    // a score far below the (running) maximum counts as maximum - 12 binades: one very low key must not move the window
-                    sm[qt] += in ? fmaxf(sx[e], mx[qt] - span) : 0.f;
-                    cn[qt] += in ? 1.f : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const bool in = (e <= lim);
+                        mx[qt] = in ? fmaxf(mx[qt], sx[e]) : mx[qt];
+                        // a score far below the (running) maximum counts as maximum - 12 binades: one very low key must not move the window
+                        sm[qt] += in ? fmaxf(sx[e], mx[qt] - span) : 0.f;
+                        cn[qt] += in ? 1.f : 0.f;
+                    }
+                } else {
+                    // the common form, kept short (96 vector instructions per wave and pass): maximum by v_max3, plain sum (a very
+                    // low score only widens the gap, i.e. opens the window further down: the safe side)
+                    mx[qt] = fmaxf(fmaxf(mx[qt], sx[0]), sx[1]);
+                    mx[qt] = fmaxf(fmaxf(mx[qt], sx[2]), sx[3]);
+                    sm[qt] += sx[0]; sm2[qt] += sx[1]; sm[qt] += sx[2]; sm2[qt] += sx[3];
                 }
             }
         };
@@ -277,10 +302,11 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         } else {
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) tile_stats(std::false_type{}, kt);
+            cn[0] = cn[1] = 32.f;                                         // (8 tiles x 4 keys per lane)
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float m = mx[qt], u = sm[qt], n = cn[qt];
+            float m = mx[qt], u = sm[qt] + sm2[qt], n = cn[qt];
             m = fmaxf(m, __shfl_xor(m, 16));   u += __shfl_xor(u, 16);   n += __shfl_xor(n, 16);
             m = fmaxf(m, __shfl_xor(m, 32));   u += __shfl_xor(u, 32);   n += __shfl_xor(n, 32);
             const float gap = (m - u * __builtin_amdgcn_rcpf(fmaxf(n, 1.f))) * c;               // 0 .. 12 binades
@@ -298,9 +324,12 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         dma_k(2, 2 * TILE);
         dma_v(1, TILE);
     };
+    FA8_PHASE(10);              // (diagnostic) offsets, addresses, accumulator init
     if (pass == 0) issue_prologue();
+    FA8_PHASE(11);              // (diagnostic) prologue DMAs issued
     dma_wait<3 * CPT>();        // this wave's pieces of K(0), V(0) have landed ...
     __syncthreads();            // ... and every wave's are visible
+    FA8_PHASE(0);               // pass start -> first tiles visible
 
     int stage_k = 0;                               // ring stage of tile j
     auto sync_and_stage = [&](int j) {
@@ -339,6 +368,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     // Fragments are read TWO regions ahead of their MFMAs (region R reads key tile R + 2 and the V^T fragment of region
     // R + 2's product into the buffer region R has just consumed): an LDS read has a whole region to land instead of a few instructions.
     // VRD = the V^T reads of regions 0..6 (tile n - 1), VRD7 = that of region 7 (first fragment of tile n, behind the address advance).
+#if FA8_HALF_PRIO
+    const int late_half = (wave >= 4) ? 1 : 0;
+#endif
     auto block8 = [&] __device__ (auto par_c, auto do_s_c, auto sl0_c, auto sl_c, auto pv_c, auto mask_c, auto first_c, auto vrd_c, auto vrd7_c, bool do_sync, int n) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool VRD = decltype(vrd_c)::value, VRD7 = decltype(vrd7_c)::value;
@@ -348,6 +380,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         auto region = [&] __device__ (auto r_c) {
             constexpr int R = decltype(r_c)::value;
             __builtin_amdgcn_sched_barrier(0);
+#if FA8_HALF_PRIO
+            // behind the block's barrier (end of region 3) both waves of a SIMD start regions 4..7 together and the older one
+            // wins every issue arbitration: it runs them in 1180 cycles, the younger in 2460, and then waits 1700 cycles at the
+            // next barrier (profiles/r3_stamps_cfg5.txt).  Priority for the younger half in exactly those regions evens it out.
+            if constexpr (R == 4) setprio_if<1>(late_half);
+            if constexpr (R == 0) setprio_if<0>(late_half);
+#endif
             // the score MFMAs go first: their results are the next region's first VALU operands
             if constexpr (DO_S) {
 #pragma unroll
@@ -386,7 +425,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 #endif
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (R == 3) {
+#if defined(FA_STAMP)
+                st_a = stamp_now();
+#endif
                 if (do_sync) sync_and_stage(n);
+#if defined(FA_STAMP)
+                st_b = stamp_now();
+#endif
             }
         };
         region(IC<0>{}); region(IC<1>{}); region(IC<2>{}); region(IC<3>{});
@@ -409,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     int j = 0;
     if (NT > 0) {
         set_reference_from_first_block(0 >= (min(CAUSAL ? (max(0, q0w + coff) >> 7) : 0x7fffffff, Sk >> 7)));   // (block 0 needs the mask)
+        FA8_PHASE(1);           // reference pre-pass over the first block
         read_k(IC<0>{}, IC<0>{});
         read_k(IC<1>{}, IC<1>{});
         // block 0 (pipeline fill): scores and slices only (the reference is fixed: pre-pass above)
@@ -416,18 +462,34 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         swap_pf();
         stage_k = (stage_k + 1) & (kStages - 1);
         j = 1;
+        FA8_PHASE(2);           // fill block
         const int ja = min(mb, NT);
         for (; j + 1 < ja; j += 2) {                   // steady state: pairs of unmasked blocks
+#if defined(FA_STAMP)
+            const unsigned long long t0 = stamp_now();
+#endif
             block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, Y{}, Y{}, true, j);
             stage_k = (stage_k + 1) & (kStages - 1);
+#if defined(FA_STAMP)
+            const unsigned long long t1 = stamp_now();
+            st_e += st_a - t0; st_w += st_b - st_a; st_o += t1 - st_b;
+#endif
             block8(IC<1>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, Y{}, Y{}, true, j + 1);
             stage_k = (stage_k + 1) & (kStages - 1);
+#if defined(FA_STAMP)
+            const unsigned long long t2 = stamp_now();
+            st_e += st_a - t1; st_w += st_b - st_a; st_o += t2 - st_b; st_n += 2;
+#endif
         }
+#if defined(FA_STAMP)
+        st_last = stamp_now();  // (the steady loop's cycles are kept in the segment sums)
+#endif
         for (; j < NT; ++j) {                          // an odd block out, diagonal / ragged blocks: masked form + buffer swap
             block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, Y{}, N_{}, Y{}, Y{}, true, j);
             swap_pf();
             stage_k = (stage_k + 1) & (kStages - 1);
         }
+        FA8_PHASE(3);           // an odd block out, masked (diagonal / ragged) blocks
         // drain, "block" NT: the last slice, P V of block NT - 1 (tiles 0..6) and of block NT - 2 (tile 7) ...
         const bool sync_d = j < nt;
         block8(IC<0>{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, N_{}, sync_d, j);
@@ -445,6 +507,10 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     // ---- exact fallback (rare): per-block online softmax with running maximum and rescale, P = exp2(score - max + 7) <= 128.
     // Trigger: a P beyond e4m3's range turns into NaN in the conversion (v_cvt_pk_fp8_f32 under the default float mode:
     // tools/probes/cvt_fp8_probe.cpp) and poisons the row's rounded sum on the matrix pipe -- no per-score bookkeeping.
+#if FA8_HALF_PRIO
+    setprio_if<0>(late_half);
+#endif
+    FA8_PHASE(5);               // drain + staging-only tiles
     float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
     dma_wait<0>();
     bool bad_row = !(l_acc[0][0] < kPLimit8 && l_acc[1][0] < kPLimit8);
@@ -561,11 +627,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         __syncthreads();
     }
 
+    FA8_PHASE(6);               // fallback check (two barriers: waiting for the slowest wave)
     if (pass + 1 < n_pass) {
         issue_prologue();
         load_q(tq, lane_here());
     }
 
+    FA8_PHASE(7);               // (the next pass's prologue issue)
     // ---- epilogue (as fa_fwd_kernel16.hpp)
     const int lane_e = lane_here();
 #pragma unroll
@@ -592,7 +660,19 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             if (qrow < S && col < p.dv) *reinterpret_cast<u32x4*>(orow + col) = outv;
         }
     }
+    FA8_PHASE(4);               // epilogue: normalise, store
   }  // pass
+#undef FA8_PHASE
+#if defined(FA_STAMP)
+    if (lane_here() == 0 && blockIdx.x < 8192) {
+        unsigned long long* d = g_fa_stamp + ((size_t)blockIdx.x * 8 + wave) * 24;
+        unsigned long long st_rt1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1) :: "memory");
+        d[0] = st_e; d[1] = st_w; d[2] = st_o; d[3] = st_n; d[4] = stamp_now() - st_t0; d[5] = st_rt1 - st_rt0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d[8 + i] = st_ph[i];
+    }
+#endif
 }
 
 }  // namespace fa

@@ -16,18 +16,26 @@ ap.add_argument("--causal", type=int, default=0)
 ap.add_argument("--B", type=int, default=8)
 ap.add_argument("--H", type=int, default=32)
 ap.add_argument("--S", type=int, default=4096)
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"])
 a = ap.parse_args()
 lib = fa.load_library()
 lib.fa_debug_read_stamps.restype = ctypes.c_int
 lib.fa_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-q, k, v = (torch.randn(a.B, a.H, a.S, 128, device="cuda").to(torch.bfloat16) for _ in range(3))
+descale = None
+if a.dtype == "fp8":
+    f32 = [torch.randn(a.B, a.H, a.S, 128, device="cuda") for _ in range(3)]
+    descale = tuple(float(t.abs().max()) / 448.0 for t in f32)
+    q, k, v = [(t / s_).to(torch.float8_e4m3fn) for t, s_ in zip(f32, descale)]
+    del f32
+else:
+    q, k, v = (torch.randn(a.B, a.H, a.S, 128, device="cuda").to(torch.bfloat16) for _ in range(3))
 for _ in range(30):
-    fa.flash_attn(q, k, v, bool(a.causal))
+    fa.flash_attn(q, k, v, bool(a.causal), descale=descale)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20):
-    fa.flash_attn(q, k, v, bool(a.causal))
+    fa.flash_attn(q, k, v, bool(a.causal), descale=descale)
 e1.record()
 torch.cuda.synchronize()
 wall_us = e0.elapsed_time(e1) / 20 * 1e3
@@ -39,7 +47,10 @@ f = buf.astype(np.float64)
 tiles = f[:, :, 3]
 ok = tiles > 0
 print(f"workgroups {n_wg}, stamped tiles per wave: mean {tiles[ok].mean():.1f}")
-print("wave   even-block   wait+barrier   odd-block(+DMA)   total   [cycles per tile, mean over workgroups]")
+if a.dtype == "fp8":
+    print("wave   regions 0-3   wait+barrier+DMA issue   regions 4-7   total   [cycles per 128-key block, mean over workgroups]")
+else:
+    print("wave   even-block   wait+barrier   odd-block(+DMA)   total   [cycles per tile, mean over workgroups]")
 for w in range(8):
     m = ok[:, w]
     e, wt, o = [(f[m, w, i] / tiles[m, w]).mean() for i in range(3)]
@@ -54,6 +65,10 @@ print(f"whole kernel per wave: {tot.mean():.0f} cycles, of which the stamped ste
 names = ["pass start -> first tiles visible", "fill iteration", "unrolled steady loop", "leftover unmasked tiles", "masked tiles",
          "drain + staging-only tiles", "fallback check", "epilogue (+ next prologue issue)",
          "  entry: parameters, decode, descriptors", "  Q loads issued", "  offsets, addresses, accumulator init", "  prologue DMAs issued"]
+if a.dtype == "fp8":
+    names = ["pass start -> first tiles visible", "reference pre-pass (first block)", "fill block + steady pairs", "odd block out, masked blocks",
+             "epilogue: normalise, store", "drain + staging-only tiles", "fallback check (two barriers)", "next pass's prologue issue",
+             "  entry: parameters, decode, descriptors", "  Q loads issued", "  offsets, addresses, accumulator init", "  prologue DMAs issued"]
 print("(the first phase below is what remains after the four indented entry sub-phases: the wait for Q / K(0) and the barrier)")
 print("phases, cycles per workgroup (sum over its passes), mean over waves [older waves 0-3 | younger 4-7]:")
 ph = f[:, :, 8:20].copy()
@@ -73,7 +88,7 @@ print("by dispatch round (blockIdx // 256): whole workgroup | pass start -> firs
 for r in range(rounds):
     sl = slice(r * n_cu, min(n_wg, (r + 1) * n_cu))
     print(f"  round {r}: {f[sl, :, 4].mean():9.0f} | {ph[sl, :, 0].mean():8.0f} | {ph[sl, :, 9].mean():8.0f} | {ph[sl, :, 11].mean():8.0f}")
-# per wave (causal: wave w < 4 owns row block w, wave w >= 4 row block 11 - w): the phases around the end of a pass
-print("per wave: pass start | fill | leftover | masked | drain+staging-only | fallback check (own stores, the barrier) | epilogue")
+# per wave (causal: wave w < 4 owns row block w, wave w >= 4 row block 11 - w): the phases of a pass
+print("per wave, phases 0-7 in the order listed above (cycles per workgroup):")
 for w in range(8):
-    print(f"  wave {w}: " + " | ".join(f"{ph[:, w, i].mean():8.0f}" for i in (0, 1, 3, 4, 5, 6, 7)))
+    print(f"  wave {w}: " + " | ".join(f"{ph[:, w, i].mean():8.0f}" for i in range(8)))
