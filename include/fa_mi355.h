@@ -99,6 +99,12 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
  * workspace by a HIP pre-pass and the bf16 kernel runs.  The q, k dequantisation scales are folded into the softmax
  * scale, the v scale into the output.  No reference counterpart (the reference is fp16 only); BASELINE.json
  * config 5.  Stated accuracy for fp8 inputs: relative Frobenius error <= 5 %.
+ *   Where P sits in e4m3's range is chosen per row from the scores of its FIRST 128 KEYS (reference = their maximum; window
+ *   opened downwards by how far the rest of the sample lies below it).  Known limitation: a row whose first 128 keys are ALL
+ *   far above a tail that still carries a large share of the softmax weight (> 9 binades below them) loses that tail to e4m3's
+ *   underflow.  With lse != NULL the kernel forms the exact row sums anyway, notices that the rounded sum falls short
+ *   (< 0.92 of the exact one) and redoes the workgroup with its exact running-maximum loop; with lse == NULL there is nothing
+ *   to compare with and the loss is silent: a caller that cannot rule such inputs out passes an LSE buffer (cost ~4 %).
  *   strides are in elements (= bytes) with unit head_dim stride; rows and bases 16-byte aligned.
  *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes, 16-byte aligned (0 bytes for
  *              head_dim > 64: the pointer may then be NULL; three bf16 tensors otherwise).
