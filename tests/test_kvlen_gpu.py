@@ -103,6 +103,26 @@ def test_reference_generated_key_length_fixtures(name):
         assert_grad_close(got, d[key], dt, f"{name}:{key}")
 
 
+@pytest.mark.parametrize("Sq,Sk", [(2048, 2304), (2048, 2560), (1792, 2112)])
+def test_paired_causal_blocks_with_a_longer_key_sequence(Sq, Sk):
+    """A launch large enough for the paired schedule (two query blocks per workgroup, the staging ring running on from the first
+    block into the second -- `cont` in fa_fwd_kernel16.hpp -- whenever S_k - S_q is a multiple of 256; (1792, 2112) is the case
+    where it is not and the second block gets its own prologue) with the bottom-right aligned mask: the forward of the S_q x S_k
+    problem is the tail of the product's own square S_k x S_k run, block-aligned offsets bitwise."""
+    B, H, D = 1, 64, 128
+    g = torch.Generator().manual_seed(Sq + Sk)
+    qf, k, v = [torch.randn(B, H, Sk, D, generator=g).bfloat16().cuda() for _ in range(3)]
+    q = qf[:, :, Sk - Sq:].contiguous()
+    o, lse = fa.flash_attn(q, k, v, True, return_lse=True)
+    o_sq, lse_sq = fa.flash_attn(qf, k, v, True, return_lse=True)
+    assert torch.isfinite(o.float()).all()
+    assert (o.float() - o_sq[:, :, Sk - Sq:].float()).abs().max() <= TOL["bf16"]
+    assert (lse - lse_sq[:, :, Sk - Sq:]).abs().max() <= 2e-3
+    if (Sk - Sq) % 256 == 0:
+        assert torch.equal(o, o_sq[:, :, Sk - Sq:])
+    assert torch.equal(fa.flash_attn(q, k, v, True), o)
+
+
 @pytest.mark.parametrize("Sq,Sk,D", [(128, 512, 128), (90, 347, 128), (256, 1024, 64)])
 def test_causal_tail_of_the_square_problem(Sq, Sk, D):
     """The S_q x S_k causal problem against the product's own square S_k x S_k run (rows S_k - S_q ..)."""
