@@ -437,7 +437,7 @@ def main():
         # after the timed region and outside `value`: a failure here (a collective the backend lacks, memory) must not cost
         # the run its bench line -- but it must be collective-safe, so every rank takes the same path and reports its error
         try:
-            gather = time_gather(dist, fa, q, k, v, causal, descale, world, args.gather_chunks, barrier, dev)
+            gather = time_gather(dist, fa, q, k, v, causal, descale, world, args.gather_chunks, barrier, dev, backend)
         except Exception as e:  # noqa: BLE001
             gather = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -508,7 +508,7 @@ def main():
         dist.destroy_process_group()
 
 
-def time_gather(dist, fa, q, k, v, causal, descale, world, chunks, barrier, dev):
+def time_gather(dist, fa, q, k, v, causal, descale, world, chunks, barrier, dev, backend="nccl"):
     """The final assembly of O (SURVEY.md §8e): (i) one blocking all_gather_into_tensor of the rank's whole shard;
     (ii) the shard cut into `chunks` batch slices, the kernel of slice i+1 on the compute stream beside the all-gather
     of slice i on a second stream.  Both after the timed region; neither is part of `value`."""
@@ -535,7 +535,7 @@ def time_gather(dist, fa, q, k, v, causal, descale, world, chunks, barrier, dev)
     out = {"ms": g_ms, "shard_MiB": shard / 2 ** 20,
            "recv_GBps_per_rank": (world - 1) * shard / (g_ms * 1e-3) / 1e9,
            "compute_then_gather_ms": serial_ms,
-           "note": "all_gather_into_tensor of O over RCCL, outside the timed region"}
+           "note": f"all_gather_into_tensor of O over {'RCCL' if backend == 'nccl' else backend + ' (rehearsal: CPU collectives)'}, outside the timed region"}
     chunks = max(1, min(chunks, B))
     if chunks > 1 and B % chunks == 0:
         bc = B // chunks
