@@ -123,6 +123,20 @@ def test_paired_causal_blocks_with_a_longer_key_sequence(Sq, Sk):
     assert torch.equal(fa.flash_attn(q, k, v, True), o)
 
 
+def test_paired_causal_blocks_with_a_shorter_key_sequence():
+    """S_q > S_k under the bottom-right aligned mask at the paired schedule's scale: the first S_q - S_k queries see no key
+    (O = 0, LSE = -inf), the others are the square S_k x S_k problem of the remaining queries -- including the workgroup whose
+    second query block has no key tile at all while the ring has already staged "its" first tiles."""
+    B, H, D, Sq, Sk = 1, 64, 128, 2304, 2048
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B, H, Sq, D, generator=g).bfloat16().cuda()
+    k, v = [torch.randn(B, H, Sk, D, generator=g).bfloat16().cuda() for _ in range(2)]
+    o, lse = fa.flash_attn(q, k, v, True, return_lse=True)
+    o_sq, lse_sq = fa.flash_attn(q[:, :, Sq - Sk:].contiguous(), k, v, True, return_lse=True)
+    assert (o[:, :, :Sq - Sk] == 0).all() and torch.isinf(lse[:, :, :Sq - Sk]).all()
+    assert torch.equal(o[:, :, Sq - Sk:], o_sq) and torch.equal(lse[:, :, Sq - Sk:], lse_sq)
+
+
 @pytest.mark.parametrize("Sq,Sk,D", [(128, 512, 128), (90, 347, 128), (256, 1024, 64)])
 def test_causal_tail_of_the_square_problem(Sq, Sk, D):
     """The S_q x S_k causal problem against the product's own square S_k x S_k run (rows S_k - S_q ..)."""
