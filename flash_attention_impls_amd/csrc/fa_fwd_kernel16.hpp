@@ -40,6 +40,9 @@
 // FA_PP: "ping-pong" main loop at head_dim 128 (see the PP branch of the kernel): the two waves of a SIMD alternate a
 // matrix-only phase with a load / softmax phase, one barrier per phase.  Experiment; results are
 // bitwise those of the default loop.
+#ifndef FA_S_CHAIN
+#define FA_S_CHAIN 0
+#endif
 #ifndef FA_HALF_PRIO
 #define FA_HALF_PRIO 1
 #endif
@@ -416,12 +419,21 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             return;
         }
 #endif
+#if FA_S_CHAIN          // experiment: the four k-steps of one accumulator back to back (a dependent chain), then the other query tile
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if constexpr (QK8) s_acc[par][kt][qt] = mfma16_fp8(kf8[ks], qf8[qt][ks], s_acc[par][kt][qt]);
+                else s_acc[par][kt][qt] = T::mfma16(kf[ks], qf[qt][ks], s_acc[par][kt][qt]);
+#else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
                 if constexpr (QK8) s_acc[par][kt][qt] = mfma16_fp8(kf8[ks], qf8[qt][ks], s_acc[par][kt][qt]);
                 else s_acc[par][kt][qt] = T::mfma16(kf[ks], qf[qt][ks], s_acc[par][kt][qt]);
+#endif
     };
     auto advance = [&](int dk, int dv) {
 #pragma unroll

@@ -308,7 +308,7 @@ class FlashAttnFn(torch.autograd.Function):
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, *,
                softmax_scale: float | None = None, return_lse: bool = False,
-               descale: tuple[float, float, float] | None = None):
+               descale: tuple[float, float, float] | None = None, fp8_checked: bool = False):
     """Fused attention forward on MI355X.  ``q, k, v``: (B, H, N, D) GPU tensors; ``k, v`` may have fewer heads
     (B, H_kv, N_k, D) with H % H_kv == 0 (grouped-query / multi-query attention; dk, dv then have H_kv heads too) and a
     length N_k of their own; with ``causal`` the mask is then bottom-right aligned (key j visible to query i iff
@@ -318,6 +318,9 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural
     log-sum-exp of the scaled scores (the reference keeps m and l instead: lse = m + ln l).
     ``descale`` = (q, k, v) per-tensor dequantisation scales of float8_e4m3fn inputs (rejected for other dtypes).
+    ``fp8_checked=True`` (float8 inputs): run the kernel variant that forms the exact row sums even when no LSE is asked for, so
+    that weight lost below e4m3's range is noticed and the rows redone exactly (include/fa_mi355.h, fa_fwd_fp8: the one input
+    class the default variant cannot notice -- a row whose first 128 keys ALL stand far above a heavy tail); costs a few per cent.
     Differentiable like the reference's entry point: when autograd is recording and an input requires
     grad, the HIP backward kernels produce dq, dk, dv (bf16 / fp16 / fp32-via-fp16 inputs).
     """
@@ -353,7 +356,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     if needs_grad:
         o, lse = FlashAttnFn.apply(q, k, v, bool(causal), float(softmax_scale))
     else:
-        o, lse = _fwd_raw(lib, q, k, v, bool(causal), float(softmax_scale), descale, return_lse)
+        want_lse = return_lse or (fp8_checked and code == FA_DTYPE_FP8_E4M3)
+        o, lse = _fwd_raw(lib, q, k, v, bool(causal), float(softmax_scale), descale, want_lse)
     if orig_dtype == torch.float32:
         o = o.to(orig_dtype)                              # FA2-triton.py:244
     return (o, lse) if return_lse else o

@@ -253,6 +253,8 @@ def test_fp8_a_whole_first_block_of_dominant_keys_is_caught_where_the_exact_sums
     assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
     o2 = fa.flash_attn(q, k, v, False, descale=ds).double().cpu().numpy()
     assert np.isfinite(o2).all()
+    # the Python switch for callers that want the check without the LSE
+    assert torch.equal(fa.flash_attn(q, k, v, False, descale=ds, fp8_checked=True), o)
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 2, 128, 128, 128), (2, 3, 3, 333, 333, 128), (1, 4, 2, 777, 777, 128), (1, 2, 2, 1, 1, 128),
