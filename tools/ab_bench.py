@@ -25,11 +25,12 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"])
+ap.add_argument("--zeros", type=int, default=0, help="1: all-zero inputs (the chip then holds its full clock: compares builds by cycles, not by energy)")
 a = ap.parse_args()
 
 torch.manual_seed(0)
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.float8_e4m3fn}[a.dtype]
-q, k, v = (torch.randn(a.B, a.H, a.S, a.D, device="cuda").to(DT) for _ in range(3))
+q, k, v = ((torch.zeros if a.zeros else torch.randn)(a.B, a.H, a.S, a.D, device="cuda").to(DT) for _ in range(3))
 libs = [fa_mod.load_library(p) for p in a.libs]
 ref = None
 times = {p: [] for p in a.libs}
