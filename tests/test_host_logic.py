@@ -38,6 +38,19 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert os.path.dirname(_build.LIB_PATH) == os.path.dirname(fa.__file__)   # in-tree .so
 
 
+def test_diagnostic_entries_without_gpu():
+    """fa_device_cus falls back to a whole MI355X (256 CUs) when no device can be queried; fa_diag_mfma_loop rejects bad
+    arguments before any launch."""
+    lib = fa.load_library()
+    assert lib.fa_device_cus() in (256, 128, 64, 32) or lib.fa_device_cus() > 0
+    import ctypes
+    fl = ctypes.c_double(0.0)
+    assert lib.fa_diag_mfma_loop(0, 10, None, None, ctypes.byref(fl), None) == -5        # FA_ERR_NULL_PTR
+    buf = (ctypes.c_char * 64)()
+    assert lib.fa_diag_mfma_loop(0, 0, ctypes.addressof(buf) // 16 * 16 + 16, ctypes.addressof(buf), ctypes.byref(fl), None) == -3   # iters <= 0
+    assert b"iters" in lib.fa_last_error()
+
+
 def test_supported_matrix():
     lib = fa.load_library()
     assert lib.fa_fp8_workspace_bytes(8, 32, 4096, 128) == 0 and lib.fa_fp8_pv_native() == 1   # head_dim > 64: all three tensors feed fp8 MFMAs
