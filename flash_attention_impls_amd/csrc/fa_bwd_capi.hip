@@ -12,6 +12,8 @@
 #include "fa_capi_common.hpp"
 #include "fa_bwd_kernel.hpp"
 #include "fa_bwd_dkdv_kernel.hpp"
+#include "fa_bwd_dq_gemm_kernel.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -37,22 +39,51 @@ int launch_bwd(const fa::BwdParams& p, int grid, hipStream_t stream)
 // dK / dV: wave-specialised workgroups (fa_bwd_dkdv_kernel.hpp: a score wave and a gradient wave per SIMD).
 // -DFA_BWD_DKDV_SINGLE selects MODE 1 of fa_bwd_kernel.hpp instead (one wave per SIMD doing everything: 4-8 % slower
 // on cfg3, kept as a tuning option)
-template <class T, int D, bool CAUSAL>
+template <class T, int D, bool CAUSAL, bool WDS = false>
 int launch_dkdv(const fa::BwdParams& p, int grid, hipStream_t stream)
 {
 #if defined(FA_BWD_DKDV_SINGLE)
     return launch_bwd<T, D, 1, CAUSAL>(p, grid, stream);
 #else
     constexpr int lds = fa::dkdv_lds_bytes<D>();
-    auto* kernel = &fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>;
+    auto* kernel = &fa::fa_bwd_dkdv_kernel<T, D, CAUSAL, WDS>;
     struct Tag {};                                    // (local to this instantiation of the launcher)
     const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((fa::fa_bwd_dkdv_kernel<T, D, CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((fa::fa_bwd_dkdv_kernel<T, D, CAUSAL, WDS>), dim3(grid), dim3(512), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "dK/dV kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
+#endif
+}
+
+// dQ = scale * dS . K over the hand-off workspace (fa_bwd_dq_gemm_kernel.hpp)
+template <class T, int D, bool CAUSAL>
+int launch_dq_gemm(const fa::BwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::dqg_lds_bytes<D>();
+    auto* kernel = &fa::fa_bwd_dq_gemm_kernel<T, D, CAUSAL>;
+    struct Tag {};
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_bwd_dq_gemm_kernel<T, D, CAUSAL>), dim3(grid), dim3(512), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "dQ GEMM kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
+// The hand-off backward: dK/dV kernel first (it writes dS), then the dQ GEMM over it.
+template <class T, int D>
+int run_bwd_ds(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s)
+{
+#if defined(FA_BWD_DKDV_SINGLE)
+    return fail(FA_ERR_LAUNCH, "this build has no dS hand-off");
+#else
+    int rc = causal ? launch_dkdv<T, D, true, true>(pk, grid_k, s) : launch_dkdv<T, D, false, true>(pk, grid_k, s);
+    if (rc != FA_OK) return rc;
+    return causal ? launch_dq_gemm<T, D, true>(pq, grid_q, s) : launch_dq_gemm<T, D, false>(pq, grid_q, s);
 #endif
 }
 
@@ -133,6 +164,28 @@ int run_reduce(const float* part, void* out, int B, int Hkv, int S, int dv, int 
     return FA_OK;
 }
 
+// Geometry of the dS hand-off workspace (fa_bwd_dq_gemm_kernel.hpp): 2 KiB units [query head][32-key slab][32-query block];
+// slabs padded to whole 64-key tiles, blocks to whole 256-row workgroups.  0: the shape does not qualify (one head's image
+// must stay inside the 2 GiB a 32-bit buffer offset reaches, with room for the two tiles the ring fetches ahead).
+size_t ds_head_bytes(int S_q, int S_k, unsigned& row_bytes)
+{
+    const unsigned long long nq8 = ((unsigned long long)(S_q + 31) / 32 + 7) / 8 * 8;
+    const unsigned long long nk2 = ((unsigned long long)(S_k + 31) / 32 + 1) / 2 * 2;
+    const unsigned long long row = nq8 * 2048, head = nk2 * row;
+    row_bytes = (unsigned)row;
+    if (head + 6 * row >= (1ull << 31)) return 0;
+    return (size_t)head;
+}
+
+bool ds_enabled()
+{
+#if defined(FA_BWD_DS_DISABLE)      // A/B arm: the recompute path whatever the workspace
+    return false;
+#endif
+    const char* e = std::getenv("FA_MI355_BWD_DS");           // "0": never take the hand-off path (A/B, tests of the recompute path)
+    return !(e && e[0] == '0');
+}
+
 int bwd_grid(long long bh, long long blocks_per_head)
 {
     const long long g = fa_capi::grid_blocks(bh, blocks_per_head, fa_capi::head_split(bh, blocks_per_head));   // (virtual) heads padded to 8 XCD groups
@@ -155,6 +208,19 @@ size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
     int gp, qp;
     dkdv_parts(B, H_kv, H / H_kv, S_q, S_k, /*causal=*/true, gp, qp);          // (the causal mask splits further)
     return ((stats_bytes(B, H, S_q) + 255) / 256) * 256 + 2 * partial_bytes(B, H_kv, gp * qp, S_k, D);
+}
+
+size_t fa_bwd_ds_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D)
+{
+#if defined(FA_BWD_DKDV_SINGLE)
+    return 0;
+#endif
+    const size_t base = fa_bwd_ex_workspace_bytes(B, H, H_kv, S_q, S_k, D);
+    if (base == 0 || D < 16 || D > 128 || D % 16 != 0) return 0;
+    unsigned row;
+    const size_t head = ds_head_bytes(S_q, S_k, row);
+    if (head == 0) return 0;
+    return (base + 255) / 256 * 256 + (size_t)B * H * head;
 }
 
 int fa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
@@ -289,7 +355,21 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     const int grid_k = bwd_grid((long long)B * H_kv * parts, pk.nxb);
     if (grid_q <= 0 || grid_k <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     const bool c = causal != 0;
-    if (dtype == FA_DTYPE_BF16)
+    // a workspace of fa_bwd_ds_workspace_bytes selects the dS hand-off: 5 matrix products instead of 7
+    const size_t ds_need = fa_bwd_ds_workspace_bytes(B, H, H_kv, S, S_k, D);
+    const bool use_ds = ds_need != 0 && workspace_bytes >= ds_need && ds_enabled();
+    if (use_ds) {
+        unsigned row;
+        const size_t head_bytes = ds_head_bytes(S, S_k, row);
+        char* ds = static_cast<char*>(workspace) + (fa_bwd_ex_workspace_bytes(B, H, H_kv, S, S_k, D) + 255) / 256 * 256;
+        pq.ds = pk.ds = ds;
+        pq.ds_head_bytes = pk.ds_head_bytes = (long long)head_bytes;
+        pq.ds_row_bytes = pk.ds_row_bytes = row;
+        if (dtype == FA_DTYPE_BF16)
+            rc = big ? run_bwd_ds<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd_ds<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
+        else
+            rc = big ? run_bwd_ds<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd_ds<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
+    } else if (dtype == FA_DTYPE_BF16)
         rc = big ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
     else
         rc = big ? run_bwd<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);

@@ -21,12 +21,18 @@
 #pragma once
 #include "fa_bwd_kernel.hpp"
 
+#ifndef FA_BWD_DS_STORE_AUX
+#define FA_BWD_DS_STORE_AUX 2          // cache policy bits of the dS stores: 2 = nt (written once, read by the next kernel: +2.6 % over 0)
+#endif
+
 namespace fa {
 
 constexpr int kDkdvStages = 3;
 template <int D> constexpr int dkdv_lds_bytes() { return 2 * kDkdvStages * kBN * D * 2 + kDkdvStages * 1024 + 2 * 4 * 4096; }
 
-template <class T, int D, bool CAUSAL>
+// WDS: the score waves also write each block's dS to the hand-off workspace (fa_bwd_dq_gemm_kernel.hpp), two 16-byte stores
+// per lane and block in register order.
+template <class T, int D, bool CAUSAL, bool WDS = false>
 __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
 {
     constexpr int NW = 8;
@@ -128,8 +134,9 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const unsigned y2_tile_stride = (unsigned)(kBN * p.y2_ss * 2);
     const unsigned piece_base = lds_base + dwave * CPT * PIECE;
     const u32x4 rst = make_rsrc(p.stats, (unsigned)((long long)2 * bhq * p.Spad * 4));
-    auto issue_tile = [&] __device__ (int j, auto stage_c) {
+    auto issue_tile = [&] __device__ (int j, auto stage_c, auto role_c) {
         constexpr int ST = decltype(stage_c)::value;
+        if constexpr (NDMA != NW && decltype(role_c)::value == 0) return;       // (known per role: the score waves' copy of the pipeline holds no staging code)
         if (!stager) return;
         if (dwave == 0) dma16(rst, __builtin_amdgcn_readfirstlane(lds_base + STBASE + ST * 1024), g_st + (unsigned)j * (kBN * 4));
 #pragma unroll
@@ -169,14 +176,16 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     // to be visible from step 2j+1 on: the odd steps wait for it and, behind the barrier, send tile j+2 on its way into
     // the stage tile j-1 left when the gradient waves finished block 2j-1 in step 2j.
     constexpr int OPS = 2 * CPT;                                  // DMA instructions per tile and wave (wave 0: one more, issued first)
-    auto open_step = [&] __device__ (auto st_c, auto half_c, int i) {
+    // (WAITS: a wave that stages waits for its own DMAs; the score waves stage nothing -- with WDS they have stores in flight,
+    // which nothing here waits for)
+    auto open_step = [&] __device__ (auto st_c, auto half_c, int i, auto waits_c, auto role_c) {
         constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
-        if constexpr (HALF == 1) dma_wait<0>();                   // tile i/2 + 1 (issued a tile ago) has landed
+        if constexpr (HALF == 1 && decltype(waits_c)::value) dma_wait<0>();      // tile i/2 + 1 (issued a tile ago) has landed
 #if !defined(FA_BWD_ABL_NOBAR)     // timing-only build without the barrier
         __syncthreads();                                          // publishes the mailbox of block i-1 (and tile i/2 + 1), retires block i-2
 #endif
         if constexpr (HALF == 1) {
-            if ((i >> 1) + 2 < j_end) issue_tile((i >> 1) + 2, IC<(ST + 2) % NS>{});
+            if ((i >> 1) + 2 < j_end) issue_tile((i >> 1) + 2, IC<(ST + 2) % NS>{}, role_c);
         }
     };
     // one trip = one turn of the ring (6 blocks); step i = 2 j_end only drains the gradient waves.  The two roles run
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     // published; the score waves compute their first scores behind it), then one per step.
     // Outer loop: the G query heads of the group, each a complete pass of the pipeline (ring and mailbox start over
     // behind a barrier; the gradient accumulators carry on).
-    auto for_all_steps = [&] __device__ (auto&& prologue, auto&& body) {
+    auto for_all_steps = [&] __device__ (auto role_c, auto&& prologue, auto&& body) {
         if (j_begin >= j_end) return;
       for (int g = 0; g < p.G; ++g) {
         if (g > 0) {
@@ -193,11 +202,11 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
         }
         ry1 = make_rsrc(y1h, y1_bytes);
         ry2 = make_rsrc(y2h, y2_bytes);
-        issue_tile(j_begin, IC<0>{});
-        issue_tile(j_begin + 1, IC<1>{});
-        dma_wait<OPS>();                                          // tile j_begin has landed (tile j_begin + 1 stays in flight)
+        issue_tile(j_begin, IC<0>{}, role_c);
+        issue_tile(j_begin + 1, IC<1>{}, role_c);
+        if constexpr (NDMA == NW || decltype(role_c)::value == 1) dma_wait<OPS>();                                          // tile j_begin has landed (tile j_begin + 1 stays in flight)
         __syncthreads();
-        prologue();
+        prologue(g);
         for (int i = 2 * j_begin; i <= 2 * j_end; i += 2 * NS) {
             body(IC<0>{}, IC<0>{}, i);
             if (i + 1 <= 2 * j_end) body(IC<0>{}, IC<1>{}, i + 1);
@@ -240,6 +249,14 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                     asm volatile("" : "+v"(xf2[xt][ks]));
                 }
         }
+        // dS hand-off: this wave's row of units, [slab x0w / 32][NQ8 blocks][2 KiB] of the current query head
+        __amdgpu_buffer_rsrc_t ds_rsrc;
+        const unsigned ds_voff = (unsigned)lane * 16u;
+        auto ds_descriptor = [&] __device__ (long long headq) {
+            char* base = static_cast<char*>(p.ds) + headq * p.ds_head_bytes + (long long)(x0w >> 5) * p.ds_row_bytes;
+            ds_rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (x0w < S) ? p.ds_row_bytes : 0u, 0x00020000);
+        };
+        if constexpr (WDS) ds_descriptor(headq0);
         f32x4 t1[2][2][2], t2[2][2][2];            // score accumulators [block parity][y tile][x tile]
         // S and dP - delta of block BLK of the tile in ring stage ST, into register set BLK
         auto scores = [&] __device__ (auto st_c, auto blk_c) {
@@ -292,15 +309,21 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             lds_write_b128(mbox + (mo + 1024), pw[1]);
             lds_write_b128(mbox + (mo + 2048), dsw[0]);
             lds_write_b128(mbox + (mo + 3072), dsw[1]);
+            if constexpr (WDS) {                                        // unit (slab of this wave, block y0 / 32): [xt][lane][16 B]
+                const unsigned soff = (unsigned)(y0 >> 5) * 2048u;
+                __builtin_amdgcn_raw_buffer_store_b128(dsw[0], ds_rsrc, ds_voff, soff, FA_BWD_DS_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(dsw[1], ds_rsrc, ds_voff + 1024u, soff, FA_BWD_DS_STORE_AUX);
+            }
         };
-        for_all_steps(
-            [&] __device__ () {                                     // first scores (block 2 j_begin, stage 0) behind the prologue barrier
+        for_all_steps(IC<0>{},
+            [&] __device__ (int g) {                                // first scores (block 2 j_begin, stage 0) behind the prologue barrier
+                if constexpr (WDS) { if (g > 0) ds_descriptor(headq0 + g); }
                 const int i0 = 2 * j_begin;
                 if (i0 >= blk_begin_w && i0 < blk_end_w) scores(IC<0>{}, IC<0>{});
             },
             [&] __device__ (auto st_c, auto half_c, int i) {
                 constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
-                open_step(st_c, half_c, i);
+                open_step(st_c, half_c, i, std::integral_constant<bool, NDMA == NW>{}, IC<0>{});
 #if defined(FA_BWD_ABL_NOSCORE)    // timing-only build: idle score waves
                 return;
 #endif
@@ -355,11 +378,11 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
                 }
             }
         };
-        for_all_steps(
-            [&] __device__ () {},
+        for_all_steps(IC<1>{},
+            [&] __device__ (int) {},
             [&] __device__ (auto st_c, auto half_c, int i) {
                 constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
-                open_step(st_c, half_c, i);
+                open_step(st_c, half_c, i, std::true_type{}, IC<1>{});
 #if defined(FA_BWD_ABL_NOGRAD)     // timing-only build: idle gradient waves
                 return;
 #endif

@@ -72,6 +72,10 @@ struct BwdParams {
     long long o2_sb, o2_sh, o2_ss;
     float scale;                        // softmax scale
     float scale_log2;                   // scale * log2(e)
+    // dS hand-off (fa_bwd_dq_gemm_kernel.hpp): workspace of 2 KiB units [query head][32-key slab][32-query block]
+    void* ds;                           // null: recompute path
+    long long ds_head_bytes;            // slabs (even count) x ds_row_bytes, < 2 GiB
+    unsigned ds_row_bytes;              // blocks per slab (a multiple of 8) x 2048
 };
 
 template <int MODE> constexpr int bwd_waves() { return MODE == 0 ? 8 : 4; }

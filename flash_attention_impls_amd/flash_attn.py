@@ -107,6 +107,8 @@ def _declare(lib):
     lib.fa_fwd_fp8_ex.argtypes = lib.fa_fwd_fp8.argtypes[:5] + [c.c_int] * 6 + lib.fa_fwd_fp8.argtypes[9:]
     lib.fa_bwd_ex_workspace_bytes.restype = c.c_size_t
     lib.fa_bwd_ex_workspace_bytes.argtypes = [c.c_int] * 6
+    lib.fa_bwd_ds_workspace_bytes.restype = c.c_size_t
+    lib.fa_bwd_ds_workspace_bytes.argtypes = [c.c_int] * 6
     lib.fa_bwd_ex.restype = c.c_int
     lib.fa_bwd_ex.argtypes = lib.fa_bwd.argtypes[:9] + [c.c_int] * 6 + lib.fa_bwd.argtypes[13:]
     lib.fa_fwd_dispatch.restype = c.c_int
@@ -262,8 +264,28 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     return o, lse
 
 
+_ds_refused: set = set()        # (device, bytes) of hand-off workspaces the allocator has refused: not asked for again
+
+
+def _bwd_workspace(lib, dims, device):
+    """Workspace of one backward launch.  The dS hand-off (include/fa_mi355.h: fa_bwd_ds_workspace_bytes, 2 S_q S_k bytes
+    per query head on top of the row statistics) is taken when the shape qualifies, it stays under FA_MI355_BWD_DS_MAX_GIB
+    (default 16 of the 288 GB) and the allocator can provide it; otherwise the recompute path's small workspace.  (The
+    caching allocator hands the same block back call after call; no driver query on the way: hipMemGetInfo costs a launch.)"""
+    small = lib.fa_bwd_ex_workspace_bytes(*dims)
+    if os.environ.get("FA_MI355_BWD_DS", "1") != "0":
+        big = lib.fa_bwd_ds_workspace_bytes(*dims)
+        if 0 < big <= float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30 and (device, big) not in _ds_refused:
+            try:
+                return torch.empty(big, dtype=torch.uint8, device=device), big
+            except torch.cuda.OutOfMemoryError:
+                _ds_refused.add((device, big))
+    return torch.empty(small, dtype=torch.uint8, device=device), small
+
+
 def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
-    """Launch the backward (pre-pass + dQ kernel + dK/dV kernel).  Returns (dq, dk, dv), each written once."""
+    """Launch the backward: pre-pass, then either dK/dV kernel (writing dS) + dQ GEMM, or dQ kernel + dK/dV kernel
+    (recompute), by the workspace `_bwd_workspace` could get.  Returns (dq, dk, dv), each written once."""
     code = _dtype_code(q.dtype)
     B, H, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
@@ -274,8 +296,7 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     dv = torch.empty_like(dk)
     do = _kernel_ready(do.to(q.dtype))
     with _on_device(q.device) as stream, _trace_range("FA2_BWD"):
-        nbytes = lib.fa_bwd_ex_workspace_bytes(B, H, Hkv, N, Nk, D)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        ws, nbytes = _bwd_workspace(lib, (B, H, Hkv, N, Nk, D), q.device)
         rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
                            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Hkv, N, Nk, D,
                            _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(do),

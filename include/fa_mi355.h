@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 132          /* 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
+#define FA_VERSION 133          /* 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -186,6 +186,18 @@ int fa_bwd(const void* q, const void* k, const void* v, const void* o, const voi
  * smaller fa_bwd_workspace_bytes the unsplit kernel runs.
  */
 size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D);
+/*
+ * The dS hand-off backward (no counterpart in the reference, whose _bwd_kernel recomputes: FA2-triton.py:98-170).
+ * A workspace of fa_bwd_ds_workspace_bytes(...) -- fa_bwd_ex_workspace_bytes plus 2 * S_q * S_k bytes per query head,
+ * padded to 64-key x 256-query tiles (cfg3: 8 GiB) -- lets fa_bwd_ex / fa_bwd run 5 matrix products instead of 7: the
+ * dK/dV kernel writes the 16-bit dS it forms to the workspace and dQ = scale * dS . K becomes one streaming GEMM over it
+ * (flash_attention_impls_amd/csrc/fa_bwd_dq_gemm_kernel.hpp), instead of a second kernel that recomputes S, P, dP and dS.
+ * HBM capacity and bandwidth for matrix work: cfg3 causal backward 3.74 -> see DESIGN.md §4b.  dK and dV are bitwise those
+ * of the recompute path; dQ sums the same 16-bit dS values in the same key order (equal up to how the two kernels round a
+ * score).  Deterministic, no atomics.  Returns 0 where the shape does not qualify (one head's S_q x S_k image must stay
+ * below 2 GiB); with any smaller workspace, or with FA_MI355_BWD_DS=0 in the environment, the recompute path runs.
+ */
+size_t fa_bwd_ds_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D);
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
               int B, int H, int H_kv, int S_q, int S_k, int D,
               const int64_t* q_strides, const int64_t* k_strides,

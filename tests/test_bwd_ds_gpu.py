@@ -1,0 +1,156 @@
+"""GPU tests of the dS hand-off backward (dK/dV kernel writes dS, dQ = scale * dS . K as a streaming GEMM:
+csrc/fa_bwd_dq_gemm_kernel.hpp) against the recompute backward (FA_MI355_BWD_DS=0) and the float64 oracle.
+
+What is asserted: dK and dV are BITWISE those of the recompute path (the same kernel computes them; the stores of dS are
+the only difference); dQ meets the backward's stated tolerances against the oracle (tests/test_bwd_gpu.py) and agrees
+with the recompute path's dQ to a few 16-bit roundings; both paths are run-to-run deterministic; the workspace size alone
+selects the path at the C ABI.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL
+from oracle import attn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import flash_attention_impls_amd as fa  # noqa: E402
+import importlib  # noqa: E402
+
+fmod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
+REL_FRO = {"bf16": 6e-3, "fp16": 1e-3}
+
+
+def inputs(B, H, Hkv, Sq, Sk, D, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, H, Sq, D, generator=g).to(dtype).cuda()
+    k = torch.randn(B, Hkv, Sk, D, generator=g).to(dtype).cuda()
+    v = torch.randn(B, Hkv, Sk, D, generator=g).to(dtype).cuda()
+    do = torch.randn(B, H, Sq, D, generator=g).to(dtype).cuda()
+    return q, k, v, do
+
+
+def grads(q, k, v, do, causal, monkeypatch, ds: bool):
+    """(dq, dk, dv) through the library's own workspace choice, with the hand-off allowed or not."""
+    monkeypatch.setenv("FA_MI355_BWD_DS", "1" if ds else "0")
+    lib = fa.load_library()
+    scale = q.shape[-1] ** -0.5
+    o, lse = fmod._fwd_raw(lib, q, k, v, causal, scale, None, True)
+    ws, nbytes = fmod._bwd_workspace(lib, (q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3]), q.device)
+    small = lib.fa_bwd_ex_workspace_bytes(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3])
+    assert (nbytes > small) == ds, "the test means to compare the two paths"
+    out = fmod._bwd_raw(lib, q, k, v, o, lse, do, causal, scale)
+    torch.cuda.synchronize()
+    return out
+
+
+def check_against_oracle(got, ref, dt, what):
+    got = got.float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all(), what
+    err = np.abs(got - ref).max()
+    assert err <= TOL[dt] * max(1.0, np.abs(ref).max()), f"{what}: max|g-ref| = {err:.3e}"
+    nrm = np.linalg.norm(ref)
+    if nrm > 0:
+        assert np.linalg.norm(got - ref) / nrm <= REL_FRO[dt], what
+
+
+CASES = [
+    # B, H, Hkv, Sq, Sk, D, dtype, causal
+    (1, 1, 1, 64, 64, 128, "bf16", True), (1, 1, 1, 64, 64, 128, "bf16", False),
+    (2, 2, 2, 128, 128, 64, "bf16", True), (1, 3, 3, 129, 129, 64, "fp16", False),
+    (1, 2, 2, 255, 255, 128, "bf16", True), (1, 2, 2, 257, 257, 128, "fp16", True),
+    (2, 1, 1, 383, 383, 128, "bf16", False), (1, 5, 5, 96, 96, 64, "bf16", True),
+    (1, 1, 1, 31, 31, 128, "fp16", True), (1, 1, 1, 33, 33, 64, "bf16", False),
+    (1, 2, 2, 1030, 1030, 128, "bf16", True),             # several query-block pairs, ragged end
+    (1, 9, 9, 320, 320, 64, "fp16", False), (1, 1, 1, 2, 2, 64, "fp16", True),
+    (1, 2, 2, 130, 130, 96, "bf16", True), (1, 2, 2, 130, 130, 48, "bf16", False), (1, 2, 2, 200, 200, 16, "fp16", True),
+    (1, 8, 2, 300, 300, 128, "bf16", True), (2, 4, 1, 200, 200, 64, "fp16", False),       # grouped / multi-query heads
+    (1, 2, 2, 128, 512, 128, "bf16", True), (1, 2, 2, 100, 357, 64, "bf16", True),         # longer key history (mask offset)
+    (1, 2, 2, 300, 77, 128, "bf16", True), (1, 2, 2, 300, 77, 128, "bf16", False),         # fewer keys than queries
+    (1, 8, 1, 1100, 1100, 128, "bf16", True),             # a group split over workgroups (fp32 partial sums) + hand-off
+]
+
+
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D,dt,causal", CASES)
+def test_handoff_against_recompute_and_oracle(B, H, Hkv, Sq, Sk, D, dt, causal, monkeypatch):
+    q, k, v, do = inputs(B, H, Hkv, Sq, Sk, D, DT[dt], seed=Sq * 7 + D + (Sk - Sq))
+    dq1, dk1, dv1 = grads(q, k, v, do, causal, monkeypatch, ds=True)
+    dq0, dk0, dv0 = grads(q, k, v, do, causal, monkeypatch, ds=False)
+    assert torch.equal(dk1.view(torch.int16), dk0.view(torch.int16)), "dK differs from the recompute path"
+    assert torch.equal(dv1.view(torch.int16), dv0.view(torch.int16)), "dV differs from the recompute path"
+    # dQ: the same sums of 16-bit dS . K; the two kernels may round a score differently (S formed as Q K^T or K Q^T)
+    d = (dq1.float() - dq0.float()).abs().max().item()
+    assert d <= 0.5 * TOL[dt] * max(1.0, dq0.float().abs().max().item()), f"dQ: hand-off vs recompute {d:.3e}"
+    G = H // Hkv
+    ke, ve = [t.repeat_interleave(G, dim=1) for t in (k, v)]
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, ke, ve, do)], causal=causal)
+    check_against_oracle(dq0, ref[0], dt, "dq (recompute path: the case itself must be well enough conditioned)")
+    check_against_oracle(dq1, ref[0], dt, "dq")
+
+
+def test_handoff_is_deterministic(monkeypatch):
+    q, k, v, do = inputs(2, 4, 4, 777, 777, 128, torch.bfloat16, seed=11)
+    a = grads(q, k, v, do, True, monkeypatch, ds=True)
+    b = grads(q, k, v, do, True, monkeypatch, ds=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+def test_masked_dq_rows_are_zero(monkeypatch):
+    """S_k < S_q under the causal mask: the first S_q - S_k queries see no key, their dQ rows are exactly zero."""
+    q, k, v, do = inputs(1, 2, 2, 300, 77, 128, torch.bfloat16, seed=3)
+    dq, _, _ = grads(q, k, v, do, True, monkeypatch, ds=True)
+    assert not dq[:, :, : 300 - 77].any()
+    assert dq[:, :, 300 - 77:].any()
+
+
+def test_workspace_size_selects_the_path():
+    """C ABI: fa_bwd_ex with fa_bwd_ds_workspace_bytes runs the hand-off, with less the recompute path; the garbage a
+    too-small workspace never holds is not read (the recompute call gets a workspace poisoned with NaN patterns)."""
+    lib = fa.load_library()
+    B, H, S, D = 1, 4, 600, 128
+    q, k, v, do = inputs(B, H, H, S, S, D, torch.bfloat16, seed=21)
+    scale = D ** -0.5
+    o, lse = fmod._fwd_raw(lib, q, k, v, True, scale, None, True)
+    small = lib.fa_bwd_ex_workspace_bytes(B, H, H, S, S, D)
+    big = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D)
+    assert big > small + 2 * B * H * S * S
+    assert lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 40000, 40000, 128) == 0          # one head's image >= 2 GiB: does not qualify
+    outs = []
+    for nbytes in (big, big - 1, small):
+        ws = torch.full((big,), 0xFF, dtype=torch.uint8, device="cuda")            # 0xFFFF: a NaN in both 16-bit types
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        st = fmod._strides3
+        rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, H, S, S, D,
+                           st(q), st(k), st(v), st(o), st(do), st(dq), st(dk), st(dv),
+                           fmod._dtype_code(q.dtype), 1, scale, ws.data_ptr(), nbytes,
+                           torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.fa_last_error().decode()
+        torch.cuda.synchronize()
+        assert torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all()
+        outs.append((dq, dk, dv))
+    assert torch.equal(outs[1][0].view(torch.int16), outs[2][0].view(torch.int16))       # both smaller sizes: the recompute path
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))       # dK the same on both paths
+    ref = orc.naive_attention_bwd_f64(*[t.float().cpu().numpy() for t in (q, k, v, do)], causal=True)
+    check_against_oracle(outs[0][0], ref[0], "bf16", "dq (hand-off, poisoned workspace)")
+
+
+def test_full_size_cfg3_handoff(monkeypatch):
+    """BASELINE cfg3 at its defining size through the hand-off (8 GiB of dS): sampled rows of dQ against the float64
+    oracle of those rows, dK / dV bitwise the recompute path's."""
+    B, H, S, D = 8, 32, 4096, 128
+    q, k, v, do = inputs(B, H, H, S, S, D, torch.bfloat16, seed=2)
+    dq1, dk1, dv1 = grads(q, k, v, do, True, monkeypatch, ds=True)
+    dq0, dk0, dv0 = grads(q, k, v, do, True, monkeypatch, ds=False)
+    assert torch.equal(dk1.view(torch.int16), dk0.view(torch.int16))
+    assert torch.equal(dv1.view(torch.int16), dv0.view(torch.int16))
+    d = (dq1.float() - dq0.float()).abs().max().item()
+    assert d <= 0.5 * TOL["bf16"] * max(1.0, dq0.float().abs().max().item()), d
+    for (b, h) in ((0, 0), (7, 31), (3, 17)):
+        ref = orc.naive_attention_bwd_f64(*[t[b:b + 1, h:h + 1].float().cpu().numpy() for t in (q, k, v, do)], causal=True)
+        check_against_oracle(dq1[b:b + 1, h:h + 1], ref[0], "bf16", f"dq[{b},{h}]")
