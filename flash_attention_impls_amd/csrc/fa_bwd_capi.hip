@@ -220,6 +220,11 @@ size_t fa_bwd_ds_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
     unsigned row;
     const size_t head = ds_head_bytes(S_q, S_k, row);
     if (head == 0) return 0;
+    // Where it pays (profiles/r3_bwd_handoff_sweep.txt): the hand-off moves 2 S_q S_k bytes per head whatever the head_dim, the
+    // work it saves is proportional to head_dim.  head_dim > 64: +8 ... 14 % on large shapes, more on small ones.  head_dim <= 64:
+    // only while the dS image stays in the 256 MiB Infinity Cache (cfg2 +16 %, the reference's shapes +28 %); streamed through
+    // HBM it costs more than the recompute kernel it replaces (8,32,4096,64: -8 % causal, -17 % non-causal).
+    if (D <= 64 && (size_t)B * H * head > ((size_t)128 << 20)) return 0;
     return (base + 255) / 256 * 256 + (size_t)B * H * head;
 }
 

@@ -267,25 +267,37 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
 _ds_refused: set = set()        # (device, bytes) of hand-off workspaces the allocator has refused: not asked for again
 
 
-def _bwd_workspace(lib, dims, device):
-    """Workspace of one backward launch.  The dS hand-off (include/fa_mi355.h: fa_bwd_ds_workspace_bytes, 2 S_q S_k bytes
-    per query head on top of the row statistics) is taken when the shape qualifies, it stays under FA_MI355_BWD_DS_MAX_GIB
-    (default 16 of the 288 GB) and the allocator can provide it; otherwise the recompute path's small workspace.  (The
-    caching allocator hands the same block back call after call; no driver query on the way: hipMemGetInfo costs a launch.)"""
-    small = lib.fa_bwd_ex_workspace_bytes(*dims)
+def _bwd_plan(lib, dims, device):
+    """How one backward runs: ``(batches per launch, workspace, its size)``.
+
+    The dS hand-off (include/fa_mi355.h: fa_bwd_ds_workspace_bytes -- 2 S_q S_k bytes per query head on top of the row
+    statistics) is taken where the library says it qualifies and pays.  Its workspace is kept under
+    FA_MI355_BWD_DS_MAX_GIB (default 16 of the 288 GB): a batch that needs more is run in equal batch chunks, one after the
+    other through the same workspace -- (batch, head) slices are independent, and a chunk of several GiB of dS is a launch of
+    milliseconds.  If the allocator cannot provide the workspace, or FA_MI355_BWD_DS=0, the recompute path's small
+    workspace and one launch over the whole batch.  (No driver query on the way: hipMemGetInfo costs as much as a launch;
+    the caching allocator hands the same block back call after call.)"""
+    B = dims[0]
     if os.environ.get("FA_MI355_BWD_DS", "1") != "0":
-        big = lib.fa_bwd_ds_workspace_bytes(*dims)
-        if 0 < big <= float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30 and (device, big) not in _ds_refused:
+        cap = float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30
+        bc, big = B, lib.fa_bwd_ds_workspace_bytes(*dims)
+        if big > cap:
+            per = lib.fa_bwd_ds_workspace_bytes(1, *dims[1:])
+            bc = min(B, int(cap // per)) if per > 0 else 0
+            bc = -(-B // -(-B // bc)) if bc > 0 else 0                    # equal chunks: B = 40, 16 fit -> 3 launches of 14, 14, 12
+            big = lib.fa_bwd_ds_workspace_bytes(bc, *dims[1:]) if bc > 0 else 0
+        if 0 < big <= cap and (device, big) not in _ds_refused:
             try:
-                return torch.empty(big, dtype=torch.uint8, device=device), big
+                return bc, torch.empty(big, dtype=torch.uint8, device=device), big
             except torch.cuda.OutOfMemoryError:
                 _ds_refused.add((device, big))
-    return torch.empty(small, dtype=torch.uint8, device=device), small
+    small = lib.fa_bwd_ex_workspace_bytes(*dims)
+    return B, torch.empty(small, dtype=torch.uint8, device=device), small
 
 
 def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     """Launch the backward: pre-pass, then either dK/dV kernel (writing dS) + dQ GEMM, or dQ kernel + dK/dV kernel
-    (recompute), by the workspace `_bwd_workspace` could get.  Returns (dq, dk, dv), each written once."""
+    (recompute), by the workspace `_bwd_plan` could get.  Returns (dq, dk, dv), each written once."""
     code = _dtype_code(q.dtype)
     B, H, N, D = q.shape
     Hkv, Nk = k.shape[1], k.shape[2]
@@ -296,14 +308,17 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     dv = torch.empty_like(dk)
     do = _kernel_ready(do.to(q.dtype))
     with _on_device(q.device) as stream, _trace_range("FA2_BWD"):
-        ws, nbytes = _bwd_workspace(lib, (B, H, Hkv, N, Nk, D), q.device)
-        rc = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Hkv, N, Nk, D,
-                           _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(do),
-                           _strides3(dq), _strides3(dk), _strides3(dv),
-                           code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
-    if rc != 0:
-        raise RuntimeError(f"fa_bwd failed ({rc}): {lib.fa_last_error().decode()}")
+        bc, ws, nbytes = _bwd_plan(lib, (B, H, Hkv, N, Nk, D), q.device)
+        for b0 in range(0, B, bc):
+            b1 = min(B, b0 + bc)
+            qs, ks, vs, os_, dos, ls, dqs, dks, dvs = (t[b0:b1] for t in (q, k, v, o, do, lse, dq, dk, dv))   # views: batch is the outermost stride
+            rc = lib.fa_bwd_ex(qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), os_.data_ptr(), dos.data_ptr(), ls.data_ptr(),
+                               dqs.data_ptr(), dks.data_ptr(), dvs.data_ptr(), b1 - b0, H, Hkv, N, Nk, D,
+                               _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_), _strides3(dos),
+                               _strides3(dqs), _strides3(dks), _strides3(dvs),
+                               code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
+            if rc != 0:
+                raise RuntimeError(f"fa_bwd failed ({rc}): {lib.fa_last_error().decode()}")
     return dq, dk, dv
 
 

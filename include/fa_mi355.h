@@ -192,10 +192,12 @@ size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
  * padded to 64-key x 256-query tiles (cfg3: 8 GiB) -- lets fa_bwd_ex / fa_bwd run 5 matrix products instead of 7: the
  * dK/dV kernel writes the 16-bit dS it forms to the workspace and dQ = scale * dS . K becomes one streaming GEMM over it
  * (flash_attention_impls_amd/csrc/fa_bwd_dq_gemm_kernel.hpp), instead of a second kernel that recomputes S, P, dP and dS.
- * HBM capacity and bandwidth for matrix work: cfg3 causal backward 3.74 -> see DESIGN.md §4b.  dK and dV are bitwise those
- * of the recompute path; dQ sums the same 16-bit dS values in the same key order (equal up to how the two kernels round a
- * score).  Deterministic, no atomics.  Returns 0 where the shape does not qualify (one head's S_q x S_k image must stay
- * below 2 GiB); with any smaller workspace, or with FA_MI355_BWD_DS=0 in the environment, the recompute path runs.
+ * HBM capacity and bandwidth for matrix work: cfg3 causal backward 3.67 -> 3.26 ms (profiles/r3_bwd_handoff_sweep.txt).
+ * dQ, dK and dV have been bitwise those of the recompute path on every shape measured (both form the same 16-bit dS and sum
+ * dS . K in the same key order); the tests assert bitwise equality for dK and dV and the stated tolerance for dQ.  Deterministic, no atomics.  Returns 0 where the shape does not qualify (one head's S_q x S_k image must stay
+ * below 2 GiB) or the hand-off would not pay (head_dim <= 64 with more than 128 MiB of dS: the bytes moved do not shrink
+ * with the head_dim, the work saved does); with any smaller workspace, or with FA_MI355_BWD_DS=0 in the environment, the
+ * recompute path runs.
  */
 size_t fa_bwd_ds_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D);
 int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,

@@ -40,8 +40,9 @@ def grads(q, k, v, do, causal, monkeypatch, ds: bool):
     lib = fa.load_library()
     scale = q.shape[-1] ** -0.5
     o, lse = fmod._fwd_raw(lib, q, k, v, causal, scale, None, True)
-    ws, nbytes = fmod._bwd_workspace(lib, (q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3]), q.device)
-    small = lib.fa_bwd_ex_workspace_bytes(q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3])
+    dims = (q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3])
+    bc, ws, nbytes = fmod._bwd_plan(lib, dims, q.device)
+    small = lib.fa_bwd_ex_workspace_bytes(*dims)
     assert (nbytes > small) == ds, "the test means to compare the two paths"
     out = fmod._bwd_raw(lib, q, k, v, o, lse, do, causal, scale)
     torch.cuda.synchronize()
@@ -98,6 +99,23 @@ def test_handoff_is_deterministic(monkeypatch):
     b = grads(q, k, v, do, True, monkeypatch, ds=True)
     for x, y in zip(a, b):
         assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+def test_batch_chunks_through_a_capped_workspace(monkeypatch):
+    """A batch whose dS image passes FA_MI355_BWD_DS_MAX_GIB runs in equal batch chunks through one workspace: same bits."""
+    q, k, v, do = inputs(5, 2, 2, 300, 300, 128, torch.bfloat16, seed=17)
+    whole = grads(q, k, v, do, True, monkeypatch, ds=True)
+    lib = fa.load_library()
+    per = lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 300, 300, 128)
+    monkeypatch.setenv("FA_MI355_BWD_DS_MAX_GIB", repr(2.5 * per / 2 ** 30))           # two batches fit, five do not
+    bc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
+    assert bc == 2 and nbytes == lib.fa_bwd_ds_workspace_bytes(2, 2, 2, 300, 300, 128)   # 5 = 2 + 2 + 1
+    chunked = grads(q, k, v, do, True, monkeypatch, ds=True)
+    for x, y in zip(whole, chunked):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    monkeypatch.setenv("FA_MI355_BWD_DS_MAX_GIB", repr(0.5 * per / 2 ** 30))           # not even one batch fits: recompute path
+    bc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
+    assert bc == 5 and nbytes == lib.fa_bwd_ex_workspace_bytes(5, 2, 2, 300, 300, 128)
 
 
 def test_masked_dq_rows_are_zero(monkeypatch):

@@ -294,6 +294,25 @@ def test_grouped_query_entry_points_validate_without_gpu():
         fa.check_args(q, k, torch.zeros(1, 3, 8, 64))
 
 
+def test_handoff_workspace_size_rule():
+    """fa_bwd_ds_workspace_bytes: the recompute workspace plus 2 KiB per (32-key slab, 32-query block) unit of every query head,
+    slabs padded to 64-key tiles and blocks to 256-row workgroups; 0 where the shape does not qualify or would not pay."""
+    lib = fa.load_library()
+    small = lib.fa_bwd_ex_workspace_bytes(8, 32, 32, 4096, 4096, 128)
+    assert lib.fa_bwd_ds_workspace_bytes(8, 32, 32, 4096, 4096, 128) == (small + 255) // 256 * 256 + 8 * 32 * 128 * 128 * 2048   # cfg3: 8 GiB
+    assert lib.fa_bwd_ds_workspace_bytes(8, 32, 8, 4096, 4096, 128) - (lib.fa_bwd_ex_workspace_bytes(8, 32, 8, 4096, 4096, 128) + 255) // 256 * 256 \
+        == 8 * 32 * 128 * 128 * 2048                                                     # per QUERY head, whatever H_kv
+    # ragged lengths: 300 queries -> 10 blocks -> 16; 77 keys -> 3 slabs -> 4
+    base = (lib.fa_bwd_ex_workspace_bytes(1, 2, 2, 300, 77, 128) + 255) // 256 * 256
+    assert lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 300, 77, 128) == base + 2 * 4 * 16 * 2048
+    assert lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 40000, 40000, 128) == 0              # one head's image >= 2 GiB
+    assert lib.fa_bwd_ds_workspace_bytes(1, 16, 16, 16384, 16384, 128) > 0             # cfg4: 512 MiB per head
+    assert lib.fa_bwd_ds_workspace_bytes(8, 32, 32, 4096, 4096, 64) == 0               # head_dim 64, 8 GiB of dS: would not pay
+    assert lib.fa_bwd_ds_workspace_bytes(4, 8, 8, 1024, 1024, 64) > 0                  # cfg2: 64 MiB, stays in the Infinity Cache
+    assert lib.fa_bwd_ds_workspace_bytes(1, 6, 4, 8, 8, 128) == 0                      # H % H_kv != 0
+    assert lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 64, 64, 144) == 0                    # no backward above head_dim 128
+
+
 def test_concurrent_builds_compile_once_and_staleness_is_by_content(tmp_path):
     """N ranks importing the package together (bench.py under torch.distributed.run) must not race on the library:
     staleness is decided by a digest of the sources (not by modification times, which a copy of the tree may reorder),
