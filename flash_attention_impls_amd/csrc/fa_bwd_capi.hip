@@ -75,16 +75,25 @@ int launch_dq_gemm(const fa::BwdParams& p, int grid, hipStream_t stream)
 }
 
 // The hand-off backward: dK/dV kernel first (it writes dS), then the dQ GEMM over it.
+// `phase`: 0 = both kernels; experiments only (FA_MI355_BWD_PHASE, tools/exp_bwd_overlap.py): 1 = the dK/dV kernel alone, 2 = the
+// dQ GEMM alone over a workspace an earlier phase-1 call filled
 template <class T, int D>
-int run_bwd_ds(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s)
+int run_bwd_ds(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s, int phase)
 {
 #if defined(FA_BWD_DKDV_SINGLE)
     return fail(FA_ERR_LAUNCH, "this build has no dS hand-off");
 #else
-    int rc = causal ? launch_dkdv<T, D, true, true>(pk, grid_k, s) : launch_dkdv<T, D, false, true>(pk, grid_k, s);
-    if (rc != FA_OK) return rc;
+    int rc = FA_OK;
+    if (phase != 2) rc = causal ? launch_dkdv<T, D, true, true>(pk, grid_k, s) : launch_dkdv<T, D, false, true>(pk, grid_k, s);
+    if (rc != FA_OK || phase == 1) return rc;
     return causal ? launch_dq_gemm<T, D, true>(pq, grid_q, s) : launch_dq_gemm<T, D, false>(pq, grid_q, s);
 #endif
+}
+
+int ds_phase()
+{
+    const char* e = std::getenv("FA_MI355_BWD_PHASE");
+    return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
 }
 
 template <class T, int D>
@@ -295,8 +304,10 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* stats = static_cast<float*>(workspace);
 
-    int rc;
-    if (dtype == FA_DTYPE_BF16)
+    int rc = FA_OK;
+    const int phase = ds_phase();
+    if (phase == 2) {}                        // (experiment: the statistics are those of the phase-1 call)
+    else if (dtype == FA_DTYPE_BF16)
         rc = big ? run_prep<fa::TypeBF16, 128>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
                       : run_prep<fa::TypeBF16, 64>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
     else
@@ -371,9 +382,9 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
         pq.ds_head_bytes = pk.ds_head_bytes = (long long)head_bytes;
         pq.ds_row_bytes = pk.ds_row_bytes = row;
         if (dtype == FA_DTYPE_BF16)
-            rc = big ? run_bwd_ds<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd_ds<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
+            rc = big ? run_bwd_ds<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s, phase) : run_bwd_ds<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s, phase);
         else
-            rc = big ? run_bwd_ds<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd_ds<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s);
+            rc = big ? run_bwd_ds<fa::TypeF16, 128>(pq, grid_q, pk, grid_k, c, s, phase) : run_bwd_ds<fa::TypeF16, 64>(pq, grid_q, pk, grid_k, c, s, phase);
     } else if (dtype == FA_DTYPE_BF16)
         rc = big ? run_bwd<fa::TypeBF16, 128>(pq, grid_q, pk, grid_k, c, s) : run_bwd<fa::TypeBF16, 64>(pq, grid_q, pk, grid_k, c, s);
     else
