@@ -140,8 +140,9 @@ def cpu_baseline(w, target_s):
 def measured_traffic(key):
     """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
     correction + WRITE_SIZE; separate rocprofv3 --pmc runs of tools/prof_run.py, written by tools/update_traffic.py).
-    An entry counts only for the library it was measured on: it carries the digest of the kernel sources and is
-    reported as null (with a note) for any other build."""
+    An entry counts only for the kernel it was measured on: it carries the digest of the translation unit that kernel is
+    compiled from (`_build.unit_digest`: the unit and the csrc headers it includes, plus the flags; older entries: of every
+    source of the library) and is reported as null (with a note) for any other build."""
     from flash_attention_impls_amd import _build
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
@@ -150,9 +151,13 @@ def measured_traffic(key):
         ent = None
     if not ent:
         return None, "no PMC pass committed for this workload"
-    if ent.get("sources_digest") != _build.sources_digest():
+    if "unit_digest" in ent:
+        want, have = ent["unit_digest"], _build.unit_digest(ent.get("unit", "fa_capi.hip"))
+    else:
+        want, have = ent.get("sources_digest"), _build.sources_digest()
+    if want != have:
         return None, ("stale: profiles/hbm_traffic.json was measured on another build of the kernels "
-                      f"(digest {str(ent.get('sources_digest'))[:12]} != {_build.sources_digest()[:12]}); re-run tools/pmc.sh")
+                      f"(digest {str(want)[:12]} != {have[:12]}); re-run tools/pmc.sh")
     return ent.get("bytes_per_launch"), ent.get("source")
 
 

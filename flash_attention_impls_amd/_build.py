@@ -48,6 +48,34 @@ def sources_digest() -> str:
     return h.hexdigest()
 
 
+def unit_sources(unit: str) -> list:
+    """The files under csrc/ that one translation unit's DEVICE code is made of: the unit and every csrc header it includes,
+    transitively (`#include "x.hpp"`).  include/fa_mi355.h -- C declarations and the version number, host side only -- is not
+    among them."""
+    import re
+    seen, todo = [], [os.path.join(CSRC, unit)]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or os.path.dirname(f) != os.path.normpath(CSRC) or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f) as fh:
+            todo += [os.path.join(os.path.dirname(f), m) for m in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), re.M)]
+    return sorted(seen)
+
+
+def unit_digest(unit: str) -> str:
+    """sha256 of the compiler flags and of `unit_sources(unit)`: what a kernel of that translation unit was built from.
+    Counter measurements (profiles/hbm_traffic.json) are stamped with the digest of the unit their kernel lives in, so that an
+    edit to the backward's sources does not invalidate what was measured on the forward kernels, and vice versa."""
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for d in unit_sources(unit):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
     """True if the library is missing or was built from other sources.  Decided by content (a digest written next to the
     library), not by modification times: a copy of the tree to another machine may reorder those, and N ranks

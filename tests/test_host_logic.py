@@ -365,6 +365,31 @@ def test_build_digest_covers_every_kernel_source():
     assert {os.path.basename(i) for i in included} <= deps, included
 
 
+def test_traffic_stamps_follow_the_translation_unit(tmp_path):
+    """profiles/hbm_traffic.json entries are stamped with the digest of the translation unit their kernel is compiled from:
+    the unit's csrc closure covers every header the unit includes (transitively), the forward unit holds no backward source,
+    and every committed entry matches the tree (so bench.py prints a non-null `roofline.traffic` for the shipped kernels)."""
+    import json
+    import re
+    from flash_attention_impls_amd import _build
+    fwd = {os.path.basename(f) for f in _build.unit_sources("fa_capi.hip")}
+    bwd = {os.path.basename(f) for f in _build.unit_sources("fa_bwd_capi.hip")}
+    assert {"fa_capi.hip", "fa_fwd_kernel.hpp", "fa_fwd_kernel16.hpp", "fa_fwd_kernel8.hpp", "fa_fwd_kernel_wide.hpp", "fa_capi_common.hpp"} <= fwd
+    assert not any(n.startswith("fa_bwd") for n in fwd)
+    assert {"fa_bwd_capi.hip", "fa_bwd_kernel.hpp", "fa_bwd_dkdv_kernel.hpp", "fa_bwd_dq_gemm_kernel.hpp", "fa_fwd_kernel.hpp"} <= bwd
+    for unit, closure in (("fa_capi.hip", fwd), ("fa_bwd_capi.hip", bwd)):          # closed under local includes
+        for n in closure:
+            with open(os.path.join(_build.CSRC, n)) as f:
+                inc = {os.path.basename(i) for i in re.findall(r'#include\s+"([^"]+)"', f.read()) if not i.startswith("../")}
+            assert inc <= closure, (unit, n, inc - closure)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    with open(os.path.join(root, "profiles", "hbm_traffic.json")) as f:
+        entries = json.load(f)
+    assert {"cfg3", "cfg3nc", "cfg4", "cfg2", "cfg5"} <= set(entries)
+    for key, ent in entries.items():
+        assert ent["unit_digest"] == _build.unit_digest(ent["unit"]), f"{key}: measured on other kernel sources; re-run tools/pmc.sh"
+
+
 def test_graft_entry_checks_the_header_version_not_a_literal():
     """build() compares the library with FA_VERSION of include/fa_mi355.h (a literal there once lagged a version bump and
     would have failed the driver's build step); the in-tree library, the header and the Python loader agree."""

@@ -1,7 +1,9 @@
 """Write one entry of profiles/hbm_traffic.json from a tools/pmc.sh summary, stamped with the digest of the kernel
 sources the counters were measured on (bench.py reports `roofline.traffic` only for that build).
 
-  python tools/update_traffic.py <workload key> <summary.txt> [<summary.txt> ...] [--kernels substr,substr]
+  python tools/update_traffic.py <workload key> <summary.txt> [<summary.txt> ...] [--kernels=substr,substr] [--unit=fa_bwd_capi.hip]
+
+The stamp is the digest of the translation unit the kernels are compiled from (default: the forward's, fa_capi.hip).
 
 HBM bytes per launch = sum over the listed kernels of FETCH_SIZE x 2 (gfx950 correction: the counter tallies 128-byte
 requests at 64 bytes, MI355X_MICROARCH.md 'HBM') + WRITE_SIZE, both in KiB in the summaries.
@@ -17,6 +19,7 @@ from flash_attention_impls_amd import _build  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 opts = [a for a in sys.argv[1:] if a.startswith("--kernels")]
+unit = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--unit=")] or ["fa_capi.hip"])[0]
 key, files = args[0], args[1:]
 want = opts[0].split("=", 1)[1].split(",") if opts and "=" in opts[0] else None
 
@@ -40,7 +43,7 @@ try:
     data = json.load(open(path))
 except Exception:  # noqa: BLE001
     data = {}
-data[key] = {"bytes_per_launch": int(total), "sources_digest": _build.sources_digest(),
+data[key] = {"bytes_per_launch": int(total), "unit": unit, "unit_digest": _build.unit_digest(unit),
              "source": "; ".join(parts) + f" ({', '.join(os.path.relpath(f, ROOT) for f in files)}; separate rocprofv3 --pmc passes of tools/prof_run.py)"}
 json.dump(data, open(path, "w"), indent=1)
 print(key, data[key])
