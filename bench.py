@@ -477,6 +477,16 @@ def main():
             "device": torch.cuda.get_device_name(dev),
             "lib_version": lib.fa_version(),
         }
+        if fwdbwd:
+            # the backward's dS hand-off moves bytes on purpose: 2 x the bytes of the visible part of S per head,
+            # written once by the dK/dV kernel and read once by the dQ GEMM, in exchange for two matrix products
+            ds = 2.0 * B * H * S * S * 2 * (0.5 if causal else 1.0)
+            need = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D)
+            taken = need > 0 and os.environ.get("FA_MI355_BWD_DS", "1") != "0" and \
+                need <= float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30
+            out["roofline"]["handoff"] = {"taken": bool(taken), "dS_bytes_written_plus_read": ds if taken else 0.0,
+                                          "note": "deliberate traffic beyond the algorithmic bytes: the dS hand-off (5 matrix products "
+                                                  "instead of 7); FA_MI355_BWD_DS=0 selects the recompute backward"}
         if rehearsal:
             out["rehearsal"] = True
             out["rehearsal_value"] = out["value"]

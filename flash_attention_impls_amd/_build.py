@@ -69,7 +69,7 @@ def unit_digest(unit: str) -> str:
     Counter measurements (profiles/hbm_traffic.json) are stamped with the digest of the unit their kernel lives in, so that an
     edit to the backward's sources does not invalidate what was measured on the forward kernels, and vice versa."""
     h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
-    for d in unit_sources(unit):
+    for d in sorted({f for u in unit.split(",") for f in unit_sources(u)}):       # "a.hip,b.hip": a measurement over kernels of both
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
             h.update(f.read())

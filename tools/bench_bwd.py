@@ -1,4 +1,5 @@
-"""Backward timing on the box: fa_bwd (pre-pass + dQ kernel + dK/dV kernel) per BASELINE shape, and the
+"""Backward timing on the box: fa_bwd (pre-pass + dK/dV kernel writing dS + dQ GEMM; FA_MI355_BWD_DS=0: pre-pass + dQ kernel + dK/dV
+kernel, recompute) per BASELINE shape, and the
 reference harness' fwd+bwd step (FA2-triton.py:357-372: out = flash_attention(q,k,v); out.sum().backward()).
 Algorithmic FLOPs: 2.5 x forward (five S x S x D products; the two-kernel form executes seven)."""
 import argparse
