@@ -153,7 +153,8 @@ int fa_fwd_dispatch(const void* Q, const void* K, const void* V, void* O,
  *   dq,dk,dv    : [B,H,S,D] outputs of element type dtype; every element is written (no need to zero them)
  *   causal, softmax_scale : must equal the forward call's
  *   workspace   : device buffer of at least fa_bwd_workspace_bytes(B,H,S) bytes, 16-byte aligned
- * Three launches on `stream`: row statistics pre-pass, dQ kernel, dK/dV kernel.  Deterministic (no atomics).
+ * Three launches on `stream`: row statistics pre-pass, dQ kernel, dK/dV kernel -- or, with the larger workspace of
+ * fa_bwd_ds_workspace_bytes (below): pre-pass, dK/dV kernel (which also writes dS), dQ GEMM.  Deterministic (no atomics).
  */
 size_t fa_bwd_workspace_bytes(int B, int H, int S);
 int fa_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,

@@ -73,6 +73,8 @@ CASES = [
     (1, 2, 2, 128, 512, 128, "bf16", True), (1, 2, 2, 100, 357, 64, "bf16", True),         # longer key history (mask offset)
     (1, 2, 2, 300, 77, 128, "bf16", True), (1, 2, 2, 300, 77, 128, "bf16", False),         # fewer keys than queries
     (1, 8, 1, 1100, 1100, 128, "bf16", True),             # a group split over workgroups (fp32 partial sums) + hand-off
+    (1, 1, 1, 4096, 4096, 128, "bf16", True),             # 32 key blocks for 256 CUs: the query range of a key block split 8 ways
+    (1, 2, 2, 2304, 2304, 64, "fp16", False),             # the same without the mask, head_dim 64
 ]
 
 
