@@ -265,6 +265,7 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
 
 
 _ds_refused: set = set()        # (device, bytes) of hand-off workspaces the allocator has refused: not asked for again
+_plan_cache: dict = {}          # (shape, environment switches) -> (batches per launch, hand-off bytes or 0, recompute bytes)
 
 
 def _bwd_plan(lib, dims, device):
@@ -278,20 +279,27 @@ def _bwd_plan(lib, dims, device):
     workspace and one launch over the whole batch.  (No driver query on the way: hipMemGetInfo costs as much as a launch;
     the caching allocator hands the same block back call after call.)"""
     B = dims[0]
-    if os.environ.get("FA_MI355_BWD_DS", "1") != "0":
-        cap = float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30
-        bc, big = B, lib.fa_bwd_ds_workspace_bytes(*dims)
-        if big > cap:
-            per = lib.fa_bwd_ds_workspace_bytes(1, *dims[1:])
-            bc = min(B, int(cap // per)) if per > 0 else 0
-            bc = -(-B // -(-B // bc)) if bc > 0 else 0                    # equal chunks: B = 40, 16 fit -> 3 launches of 14, 14, 12
-            big = lib.fa_bwd_ds_workspace_bytes(bc, *dims[1:]) if bc > 0 else 0
-        if 0 < big <= cap and (device, big) not in _ds_refused:
-            try:
-                return bc, torch.empty(big, dtype=torch.uint8, device=device), big
-            except torch.cuda.OutOfMemoryError:
-                _ds_refused.add((device, big))
-    small = lib.fa_bwd_ex_workspace_bytes(*dims)
+    key = (dims, os.environ.get("FA_MI355_BWD_DS", "1"), os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16"))
+    sizes = _plan_cache.get(key)
+    if sizes is None:                       # (the size rules are pure functions of the shape: asked once per shape, not per call)
+        bc, big = B, 0
+        if key[1] != "0":
+            cap = float(key[2]) * 2 ** 30
+            big = lib.fa_bwd_ds_workspace_bytes(*dims)
+            if big > cap:
+                per = lib.fa_bwd_ds_workspace_bytes(1, *dims[1:])
+                bc = min(B, int(cap // per)) if per > 0 else 0
+                bc = -(-B // -(-B // bc)) if bc > 0 else 0                    # equal chunks: B = 40, 16 fit -> 3 launches of 14, 14, 12
+                big = lib.fa_bwd_ds_workspace_bytes(bc, *dims[1:]) if bc > 0 else 0
+            if not 0 < big <= cap:
+                bc, big = B, 0
+        sizes = _plan_cache[key] = (bc, big, lib.fa_bwd_ex_workspace_bytes(*dims))
+    bc, big, small = sizes
+    if big and (device, big) not in _ds_refused:
+        try:
+            return bc, torch.empty(big, dtype=torch.uint8, device=device), big
+        except torch.cuda.OutOfMemoryError:
+            _ds_refused.add((device, big))
     return B, torch.empty(small, dtype=torch.uint8, device=device), small
 
 
@@ -309,9 +317,10 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     do = _kernel_ready(do.to(q.dtype))
     with _on_device(q.device) as stream, _trace_range("FA2_BWD"):
         bc, ws, nbytes = _bwd_plan(lib, (B, H, Hkv, N, Nk, D), q.device)
+        full = (q, k, v, o, do, lse, dq, dk, dv)
         for b0 in range(0, B, bc):
             b1 = min(B, b0 + bc)
-            qs, ks, vs, os_, dos, ls, dqs, dks, dvs = (t[b0:b1] for t in (q, k, v, o, do, lse, dq, dk, dv))   # views: batch is the outermost stride
+            qs, ks, vs, os_, dos, ls, dqs, dks, dvs = full if bc >= B else (t[b0:b1] for t in full)   # views: batch is the outermost stride
             rc = lib.fa_bwd_ex(qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), os_.data_ptr(), dos.data_ptr(), ls.data_ptr(),
                                dqs.data_ptr(), dks.data_ptr(), dvs.data_ptr(), b1 - b0, H, Hkv, N, Nk, D,
                                _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_), _strides3(dos),
