@@ -186,6 +186,20 @@ size_t ds_head_bytes(int S_q, int S_k, unsigned& row_bytes)
     return (size_t)head;
 }
 
+// Where the hand-off pays (profiles/r3_bwd_handoff_sweep.txt, r3_bwd_handoff_sweep_d64.txt): it moves 2 S_q S_k bytes per head
+// -- half of that under the causal mask -- whatever the head_dim, and the work it saves is proportional to head_dim.
+// head_dim > 64: +8 ... 14 % on large shapes, more on small ones: always.  head_dim <= 64: while the dS that is actually written
+// and read stays within half of the 256 MiB Infinity Cache (+9 ... 34 % up to 64 MiB, -1 ... +25 % at 128 MiB); streamed through
+// HBM it costs more than the recompute kernel it replaces ((8,32,4096,64): -8 % causal, -17 % non-causal).
+bool ds_pays(int D, size_t image_bytes, bool causal)
+{
+#if defined(FA_BWD_DS_ALWAYS)           // (tuning builds: the hand-off wherever it qualifies, to measure where it stops paying)
+    return true;
+#endif
+    if (D > 64) return true;
+    return image_bytes / (causal ? 2 : 1) <= ((size_t)128 << 20);
+}
+
 bool ds_enabled()
 {
 #if defined(FA_BWD_DS_DISABLE)      // A/B arm: the recompute path whatever the workspace
@@ -229,11 +243,7 @@ size_t fa_bwd_ds_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
     unsigned row;
     const size_t head = ds_head_bytes(S_q, S_k, row);
     if (head == 0) return 0;
-    // Where it pays (profiles/r3_bwd_handoff_sweep.txt): the hand-off moves 2 S_q S_k bytes per head whatever the head_dim, the
-    // work it saves is proportional to head_dim.  head_dim > 64: +8 ... 14 % on large shapes, more on small ones.  head_dim <= 64:
-    // only while the dS image stays in the 256 MiB Infinity Cache (cfg2 +16 %, the reference's shapes +28 %); streamed through
-    // HBM it costs more than the recompute kernel it replaces (8,32,4096,64: -8 % causal, -17 % non-causal).
-    if (D <= 64 && (size_t)B * H * head > ((size_t)128 << 20)) return 0;
+    if (!ds_pays(D, (size_t)B * H * head, /*causal=*/true)) return 0;        // (the size is asked for without the mask: the laxer rule)
     return (base + 255) / 256 * 256 + (size_t)B * H * head;
 }
 
@@ -373,7 +383,9 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
     const bool c = causal != 0;
     // a workspace of fa_bwd_ds_workspace_bytes selects the dS hand-off: 5 matrix products instead of 7
     const size_t ds_need = fa_bwd_ds_workspace_bytes(B, H, H_kv, S, S_k, D);
-    const bool use_ds = ds_need != 0 && workspace_bytes >= ds_need && ds_enabled();
+    unsigned ds_row_probe;
+    const bool use_ds = ds_need != 0 && workspace_bytes >= ds_need && ds_enabled() &&
+                        ds_pays(D, (size_t)B * H * ds_head_bytes(S, S_k, ds_row_probe), c);
     if (use_ds) {
         unsigned row;
         const size_t head_bytes = ds_head_bytes(S, S_k, row);

@@ -309,6 +309,9 @@ def test_handoff_workspace_size_rule():
     assert lib.fa_bwd_ds_workspace_bytes(1, 16, 16, 16384, 16384, 128) > 0             # cfg4: 512 MiB per head
     assert lib.fa_bwd_ds_workspace_bytes(8, 32, 32, 4096, 4096, 64) == 0               # head_dim 64, 8 GiB of dS: would not pay
     assert lib.fa_bwd_ds_workspace_bytes(4, 8, 8, 1024, 1024, 64) > 0                  # cfg2: 64 MiB, stays in the Infinity Cache
+    assert lib.fa_bwd_ds_workspace_bytes(8, 16, 16, 1024, 1024, 64) > 0                # 256 MiB image: pays under the causal mask (128 MiB moved)
+    assert lib.fa_bwd_ds_workspace_bytes(8, 32, 32, 1024, 1024, 32) == 0               # 512 MiB image: not at head_dim <= 64
+    assert lib.fa_bwd_ds_workspace_bytes(8, 32, 32, 1024, 1024, 96) > 0                # head_dim 96 runs on the head_dim-128 kernels: always
     assert lib.fa_bwd_ds_workspace_bytes(1, 6, 4, 8, 8, 128) == 0                      # H % H_kv != 0
     assert lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 64, 64, 144) == 0                    # no backward above head_dim 128
 
