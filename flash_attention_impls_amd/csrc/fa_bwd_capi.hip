@@ -174,15 +174,15 @@ int run_reduce(const float* part, void* out, int B, int Hkv, int S, int dv, int 
 }
 
 // Geometry of the dS hand-off workspace (fa_bwd_dq_gemm_kernel.hpp): 2 KiB units [query head][32-key slab][32-query block];
-// slabs padded to whole 64-key tiles, blocks to whole 256-row workgroups.  0: the shape does not qualify (one head's image
-// must stay inside the 2 GiB a 32-bit buffer offset reaches, with room for the two tiles the ring fetches ahead).
+// slabs padded to whole 64-key tiles, blocks to whole 256-row workgroups.  Both kernels address it through descriptors of at
+// most two slab rows, so one head's image may be of any size; 0: a slab row itself would pass the 32-bit range (S_q >= 2^24).
 size_t ds_head_bytes(int S_q, int S_k, unsigned& row_bytes)
 {
     const unsigned long long nq8 = ((unsigned long long)(S_q + 31) / 32 + 7) / 8 * 8;
     const unsigned long long nk2 = ((unsigned long long)(S_k + 31) / 32 + 1) / 2 * 2;
     const unsigned long long row = nq8 * 2048, head = nk2 * row;
     row_bytes = (unsigned)row;
-    if (head + 6 * row >= (1ull << 31)) return 0;
+    if (2 * row >= (1ull << 30)) return 0;
     return (size_t)head;
 }
 

@@ -119,13 +119,14 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dq_gemm_kernel(const BwdParams 
     const unsigned y1_tile_stride = (unsigned)(kBN * p.y1_ss * 2);
     const unsigned k_piece_base = lds_base + wave * CPT * PIECE;
     const unsigned ds_piece_base = lds_base + DSBASE + wave * DSW;
-    // descriptor at this wave's column of units: [slab][NQ8 blocks][2 KiB], from (head, slab 0, block blk) to the head's end
+    // this wave's column of units, [slab][NQ8 blocks][2 KiB]: a descriptor per 64-key tile, from (slab 2 j, block blk) to the end of
+    // slab 2 j + 1's row -- a head's image may pass the 4 GiB a 32-bit offset reaches (S_q S_k >= 2^31), two slab rows never do
     const unsigned ds_row = p.ds_row_bytes;                         // NQ8 * 2048
     const char* dsh = reinterpret_cast<const char*>(p.ds) + (long long)head * p.ds_head_bytes + (long long)blk * 2048;
-    const unsigned ds_bytes = (unsigned)(p.ds_head_bytes - (long long)blk * 2048);
-    const u32x4 rds = make_rsrc(dsh, x0w < S ? ds_bytes : 0u);
+    const unsigned ds_bytes = x0w < S ? 2u * ds_row - (unsigned)blk * 2048u : 0u;
     const unsigned g_ds = (unsigned)dqg_pi(lane) * 16;
     auto issue_tile = [&](int j, int stage) {
+        const u32x4 rds = make_rsrc(dsh + (long long)j * (2ll * ds_row), ds_bytes);
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
             dma16(ry1, __builtin_amdgcn_readfirstlane(k_piece_base + stage * TILE + i * PIECE), (unsigned)j * y1_tile_stride + g_y1[i]);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dq_gemm_kernel(const BwdParams 
         for (int sg = 0; sg < 2; ++sg) {
             // a slab past this wave's range has no unit written for this block: its pieces are pushed out of the descriptor
             // (zeros, no memory traffic); the DMA count per tile stays the same for the counted waits
-            const unsigned off = (2 * j + sg < s_end_w) ? (unsigned)(2 * j + sg) * ds_row + g_ds : 0x80000000u;
+            const unsigned off = (2 * j + sg < s_end_w) ? (unsigned)sg * ds_row + g_ds : 0x80000000u;
 #pragma unroll
             for (int xt = 0; xt < 2; ++xt)
                 dma16_once(rds, __builtin_amdgcn_readfirstlane(ds_piece_base + (stage * 4 + 2 * sg + xt) * PIECE), off + xt * 1024);

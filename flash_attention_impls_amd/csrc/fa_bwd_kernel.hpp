@@ -74,7 +74,7 @@ struct BwdParams {
     float scale_log2;                   // scale * log2(e)
     // dS hand-off (fa_bwd_dq_gemm_kernel.hpp): workspace of 2 KiB units [query head][32-key slab][32-query block]
     void* ds;                           // null: recompute path
-    long long ds_head_bytes;            // slabs (even count) x ds_row_bytes, < 2 GiB
+    long long ds_head_bytes;            // slabs (even count) x ds_row_bytes
     unsigned ds_row_bytes;              // blocks per slab (a multiple of 8) x 2048
 };
 

@@ -268,39 +268,58 @@ _ds_refused: set = set()        # (device, bytes) of hand-off workspaces the all
 _plan_cache: dict = {}          # (shape, environment switches) -> (batches per launch, hand-off bytes or 0, recompute bytes)
 
 
+def _equal_parts(n: int, fit: int) -> int:
+    """Largest part size <= fit that splits n into the fewest, equal-as-possible parts (40 with 16 fitting -> 14: 14, 14, 12)."""
+    return -(-n // -(-n // fit))
+
+
 def _bwd_plan(lib, dims, device):
-    """How one backward runs: ``(batches per launch, workspace, its size)``.
+    """How one backward runs: ``(batches per launch, query heads per launch, workspace, its size)``.
 
     The dS hand-off (include/fa_mi355.h: fa_bwd_ds_workspace_bytes -- 2 S_q S_k bytes per query head on top of the row
     statistics) is taken where the library says it qualifies and pays.  Its workspace is kept under
-    FA_MI355_BWD_DS_MAX_GIB (default 16 of the 288 GB): a batch that needs more is run in equal batch chunks, one after the
-    other through the same workspace -- (batch, head) slices are independent, and a chunk of several GiB of dS is a launch of
-    milliseconds.  If the allocator cannot provide the workspace, or FA_MI355_BWD_DS=0, the recompute path's small
-    workspace and one launch over the whole batch.  (No driver query on the way: hipMemGetInfo costs as much as a launch;
-    the caching allocator hands the same block back call after call.)"""
-    B = dims[0]
-    key = (dims, os.environ.get("FA_MI355_BWD_DS", "1"), os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16"))
+    FA_MI355_BWD_DS_MAX_GIB (default 16 of the 288 GB): a launch that needs more is split into equal chunks that run one after
+    the other through the same workspace -- whole batches first; where one batch alone does not fit (long sequences: 16 heads
+    at S = 32768 are 32 GiB), groups of query heads that share a key/value head.  (batch, head) slices are independent, and a
+    chunk of several GiB of dS is a launch of milliseconds.  If not even one group fits, the allocator cannot provide the
+    workspace, or FA_MI355_BWD_DS=0: the recompute path's small workspace and one launch.  (No driver query on the way:
+    hipMemGetInfo costs as much as a launch; the caching allocator hands the same block back call after call.)"""
+    B, H, Hkv = dims[0], dims[1], dims[2]
+    key = (dims, os.environ.get("FA_MI355_BWD_DS", "1"), os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16"),
+           os.environ.get("FA_MI355_BWD_DS_MIN_BLOCKS_PER_CU", "2"))
     sizes = _plan_cache.get(key)
     if sizes is None:                       # (the size rules are pure functions of the shape: asked once per shape, not per call)
-        bc, big = B, 0
+        bc, hc, big = B, H, 0
         if key[1] != "0":
             cap = float(key[2]) * 2 ** 30
             big = lib.fa_bwd_ds_workspace_bytes(*dims)
             if big > cap:
                 per = lib.fa_bwd_ds_workspace_bytes(1, *dims[1:])
-                bc = min(B, int(cap // per)) if per > 0 else 0
-                bc = -(-B // -(-B // bc)) if bc > 0 else 0                    # equal chunks: B = 40, 16 fit -> 3 launches of 14, 14, 12
-                big = lib.fa_bwd_ds_workspace_bytes(bc, *dims[1:]) if bc > 0 else 0
+                G = H // Hkv
+                if 0 < per <= cap:
+                    bc = _equal_parts(B, min(B, int(cap // per)))
+                    big = lib.fa_bwd_ds_workspace_bytes(bc, *dims[1:])
+                elif per > cap and 0 < lib.fa_bwd_ds_workspace_bytes(1, G, 1, *dims[3:]) <= cap:
+                    groups = _equal_parts(Hkv, max(1, min(Hkv, int(cap // lib.fa_bwd_ds_workspace_bytes(1, G, 1, *dims[3:])))))
+                    bc, hc = 1, groups * G
+                    big = lib.fa_bwd_ds_workspace_bytes(1, hc, groups, *dims[3:])
+                    # a chunk must still fill the chip: with fewer than two 256-row query blocks per CU the launches of a chunk run
+                    # half empty and the split costs more than the hand-off gains ((1,8,65536,128) head by head: -1.4 %)
+                    cus = lib.fa_device_cus() if hasattr(lib, "fa_device_cus") else 256
+                    if hc * ((dims[3] + 255) // 256) < float(key[3]) * cus:
+                        big = 0
+                else:
+                    big = 0
             if not 0 < big <= cap:
-                bc, big = B, 0
-        sizes = _plan_cache[key] = (bc, big, lib.fa_bwd_ex_workspace_bytes(*dims))
-    bc, big, small = sizes
+                bc, hc, big = B, H, 0
+        sizes = _plan_cache[key] = (bc, hc, big, lib.fa_bwd_ex_workspace_bytes(*dims))
+    bc, hc, big, small = sizes
     if big and (device, big) not in _ds_refused:
         try:
-            return bc, torch.empty(big, dtype=torch.uint8, device=device), big
+            return bc, hc, torch.empty(big, dtype=torch.uint8, device=device), big
         except torch.cuda.OutOfMemoryError:
             _ds_refused.add((device, big))
-    return B, torch.empty(small, dtype=torch.uint8, device=device), small
+    return B, H, torch.empty(small, dtype=torch.uint8, device=device), small
 
 
 def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
@@ -316,18 +335,24 @@ def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     dv = torch.empty_like(dk)
     do = _kernel_ready(do.to(q.dtype))
     with _on_device(q.device) as stream, _trace_range("FA2_BWD"):
-        bc, ws, nbytes = _bwd_plan(lib, (B, H, Hkv, N, Nk, D), q.device)
-        full = (q, k, v, o, do, lse, dq, dk, dv)
+        bc, hc, ws, nbytes = _bwd_plan(lib, (B, H, Hkv, N, Nk, D), q.device)
+        G = H // Hkv
         for b0 in range(0, B, bc):
             b1 = min(B, b0 + bc)
-            qs, ks, vs, os_, dos, ls, dqs, dks, dvs = full if bc >= B else (t[b0:b1] for t in full)   # views: batch is the outermost stride
-            rc = lib.fa_bwd_ex(qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), os_.data_ptr(), dos.data_ptr(), ls.data_ptr(),
-                               dqs.data_ptr(), dks.data_ptr(), dvs.data_ptr(), b1 - b0, H, Hkv, N, Nk, D,
-                               _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_), _strides3(dos),
-                               _strides3(dqs), _strides3(dks), _strides3(dvs),
-                               code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
-            if rc != 0:
-                raise RuntimeError(f"fa_bwd failed ({rc}): {lib.fa_last_error().decode()}")
+            for h0 in range(0, H, hc):
+                h1 = min(H, h0 + hc)
+                if bc >= B and hc >= H:
+                    qs, os_, dos, ls, dqs, ks, vs, dks, dvs = q, o, do, lse, dq, k, v, dk, dv
+                else:       # views: a whole-batch chunk is a contiguous block; a head chunk (single batch) goes through the strides
+                    qs, os_, dos, ls, dqs = (t[b0:b1, h0:h1] for t in (q, o, do, lse, dq))
+                    ks, vs, dks, dvs = (t[b0:b1, h0 // G:h1 // G] for t in (k, v, dk, dv))
+                rc = lib.fa_bwd_ex(qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), os_.data_ptr(), dos.data_ptr(), ls.data_ptr(),
+                                   dqs.data_ptr(), dks.data_ptr(), dvs.data_ptr(), b1 - b0, h1 - h0, (h1 - h0) // G, N, Nk, D,
+                                   _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_), _strides3(dos),
+                                   _strides3(dqs), _strides3(dks), _strides3(dvs),
+                                   code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
+                if rc != 0:
+                    raise RuntimeError(f"fa_bwd failed ({rc}): {lib.fa_last_error().decode()}")
     return dq, dk, dv
 
 

@@ -195,8 +195,10 @@ size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
  * (flash_attention_impls_amd/csrc/fa_bwd_dq_gemm_kernel.hpp), instead of a second kernel that recomputes S, P, dP and dS.
  * HBM capacity and bandwidth for matrix work: cfg3 causal backward 3.67 -> 3.26 ms (profiles/r3_bwd_handoff_sweep.txt).
  * dQ, dK and dV have been bitwise those of the recompute path on every shape measured (both form the same 16-bit dS and sum
- * dS . K in the same key order); the tests assert bitwise equality for dK and dV and the stated tolerance for dQ.  Deterministic, no atomics.  Returns 0 where the shape does not qualify (one head's S_q x S_k image must stay
- * below 2 GiB) or the hand-off cannot pay (head_dim <= 64 with a dS image of more than 256 MiB: the bytes moved do not
+ * dS . K in the same key order); the tests assert bitwise equality for dK and dV and the stated tolerance for dQ.
+ * Deterministic, no atomics.  One head's image may be of any size (both kernels address it through descriptors of two slab
+ * rows); a caller short of memory splits the call over batches or over groups of query heads and reuses one workspace.
+ * Returns 0 where the hand-off cannot pay (head_dim <= 64 with a dS image of more than 256 MiB: the bytes moved do not
  * shrink with the head_dim, the work saved does; fa_bwd_ex, which knows the mask, takes the hand-off at head_dim <= 64 only
  * while the dS actually written and read -- half the image under the causal mask -- is at most 128 MiB, i.e. stays in the
  * Infinity Cache: profiles/r3_bwd_handoff_sweep_d64.txt); with any smaller workspace, or with FA_MI355_BWD_DS=0 in the

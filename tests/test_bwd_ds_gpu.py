@@ -41,7 +41,7 @@ def grads(q, k, v, do, causal, monkeypatch, ds: bool):
     scale = q.shape[-1] ** -0.5
     o, lse = fmod._fwd_raw(lib, q, k, v, causal, scale, None, True)
     dims = (q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3])
-    bc, ws, nbytes = fmod._bwd_plan(lib, dims, q.device)
+    bc, hc, ws, nbytes = fmod._bwd_plan(lib, dims, q.device)
     small = lib.fa_bwd_ex_workspace_bytes(*dims)
     assert (nbytes > small) == ds, "the test means to compare the two paths"
     out = fmod._bwd_raw(lib, q, k, v, o, lse, do, causal, scale)
@@ -110,14 +110,52 @@ def test_batch_chunks_through_a_capped_workspace(monkeypatch):
     lib = fa.load_library()
     per = lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 300, 300, 128)
     monkeypatch.setenv("FA_MI355_BWD_DS_MAX_GIB", repr(2.5 * per / 2 ** 30))           # two batches fit, five do not
-    bc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
-    assert bc == 2 and nbytes == lib.fa_bwd_ds_workspace_bytes(2, 2, 2, 300, 300, 128)   # 5 = 2 + 2 + 1
+    bc, hc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
+    assert (bc, hc) == (2, 2) and nbytes == lib.fa_bwd_ds_workspace_bytes(2, 2, 2, 300, 300, 128)   # 5 = 2 + 2 + 1
     chunked = grads(q, k, v, do, True, monkeypatch, ds=True)
     for x, y in zip(whole, chunked):
         assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    monkeypatch.setenv("FA_MI355_BWD_DS_MIN_BLOCKS_PER_CU", "0")                       # (head chunks of a small shape: allowed for the test)
     monkeypatch.setenv("FA_MI355_BWD_DS_MAX_GIB", repr(0.5 * per / 2 ** 30))           # not even one batch fits: recompute path
-    bc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
-    assert bc == 5 and nbytes == lib.fa_bwd_ex_workspace_bytes(5, 2, 2, 300, 300, 128)
+    bc, hc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
+    assert bc == 1 and hc == 1 and nbytes == lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 300, 300, 128)   # one batch does not fit: head by head
+    per_head = grads(q, k, v, do, True, monkeypatch, ds=True)
+    for x, y in zip(whole, per_head):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    monkeypatch.setenv("FA_MI355_BWD_DS_MAX_GIB", repr(0.1 * per / 2 ** 30))           # not even one head fits: recompute path
+    bc, hc, ws, nbytes = fmod._bwd_plan(lib, (5, 2, 2, 300, 300, 128), q.device)
+    assert (bc, hc) == (5, 2) and nbytes == lib.fa_bwd_ex_workspace_bytes(5, 2, 2, 300, 300, 128)
+
+
+def test_head_group_chunks(monkeypatch):
+    """Where one batch alone passes the cap, the launch is split by groups of query heads that share a key/value head: same bits."""
+    dims = (2, 8, 2, 300, 300, 128)                        # 4 query heads per key/value head
+    q, k, v, do = inputs(*dims, torch.bfloat16, seed=23)
+    whole = grads(q, k, v, do, True, monkeypatch, ds=True)
+    lib = fa.load_library()
+    group = lib.fa_bwd_ds_workspace_bytes(1, 4, 1, 300, 300, 128)
+    monkeypatch.setenv("FA_MI355_BWD_DS_MAX_GIB", repr(1.5 * group / 2 ** 30))         # one group fits, a batch (two groups) does not
+    bc, hc, ws, nbytes = fmod._bwd_plan(lib, dims, q.device)
+    assert (bc, hc) == (2, 8) and nbytes == lib.fa_bwd_ex_workspace_bytes(*dims)       # head chunks of so small a shape would not fill the chip
+    monkeypatch.setenv("FA_MI355_BWD_DS_MIN_BLOCKS_PER_CU", "0")
+    bc, hc, ws, nbytes = fmod._bwd_plan(lib, dims, q.device)
+    assert (bc, hc) == (1, 4) and nbytes == group
+    chunked = grads(q, k, v, do, True, monkeypatch, ds=True)
+    for x, y in zip(whole, chunked):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+def test_head_image_beyond_2gib(monkeypatch):
+    """S = 33024: one head's dS image is 2.03 GiB -- past what a 32-bit buffer offset reaches; both kernels address it through
+    descriptors of two slab rows.  Bitwise the recompute path's gradients (the float64 oracle does not fit such a shape)."""
+    q, k, v, do = inputs(1, 2, 2, 33024, 33024, 128, torch.bfloat16, seed=29)
+    lib = fa.load_library()
+    assert lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 33024, 33024, 128) > 2 * 2 ** 31
+    a = grads(q, k, v, do, True, monkeypatch, ds=True)
+    b = grads(q, k, v, do, True, monkeypatch, ds=False)
+    for x, y in zip(a, b):
+        assert torch.isfinite(x.float()).all()
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
 
 
 def test_masked_dq_rows_are_zero(monkeypatch):
@@ -139,7 +177,7 @@ def test_workspace_size_selects_the_path():
     small = lib.fa_bwd_ex_workspace_bytes(B, H, H, S, S, D)
     big = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D)
     assert big > small + 2 * B * H * S * S
-    assert lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 40000, 40000, 128) == 0          # one head's image >= 2 GiB: does not qualify
+    assert lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 40000, 40000, 128) > 2 ** 31      # one head's image may pass 2 GiB (per-tile descriptors)
     outs = []
     for nbytes in (big, big - 1, small):
         ws = torch.full((big,), 0xFF, dtype=torch.uint8, device="cuda")            # 0xFFFF: a NaN in both 16-bit types

@@ -305,7 +305,7 @@ def test_handoff_workspace_size_rule():
     # ragged lengths: 300 queries -> 10 blocks -> 16; 77 keys -> 3 slabs -> 4
     base = (lib.fa_bwd_ex_workspace_bytes(1, 2, 2, 300, 77, 128) + 255) // 256 * 256
     assert lib.fa_bwd_ds_workspace_bytes(1, 2, 2, 300, 77, 128) == base + 2 * 4 * 16 * 2048
-    assert lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 40000, 40000, 128) == 0              # one head's image >= 2 GiB
+    assert lib.fa_bwd_ds_workspace_bytes(1, 1, 1, 40000, 40000, 128) > 2 ** 31         # a head's image may pass 2 GiB: descriptors of two slab rows
     assert lib.fa_bwd_ds_workspace_bytes(1, 16, 16, 16384, 16384, 128) > 0             # cfg4: 512 MiB per head
     assert lib.fa_bwd_ds_workspace_bytes(8, 32, 32, 4096, 4096, 64) == 0               # head_dim 64, 8 GiB of dS: would not pay
     assert lib.fa_bwd_ds_workspace_bytes(4, 8, 8, 1024, 1024, 64) > 0                  # cfg2: 64 MiB, stays in the Infinity Cache
