@@ -75,7 +75,7 @@ int launch_dq_gemm(const fa::BwdParams& p, int grid, hipStream_t stream)
 }
 
 // The hand-off backward: dK/dV kernel first (it writes dS), then the dQ GEMM over it.
-// `phase`: 0 = both kernels; experiments only (FA_MI355_BWD_PHASE, tools/exp_bwd_overlap.py): 1 = the dK/dV kernel alone, 2 = the
+// `phase`: 0 = both kernels; experiment builds only (-DFA_BWD_EXPERIMENTS, FA_MI355_BWD_PHASE, tools/exp_bwd_overlap.py): 1 = the dK/dV kernel alone, 2 = the
 // dQ GEMM alone over a workspace an earlier phase-1 call filled
 template <class T, int D>
 int run_bwd_ds(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int grid_k, bool causal, hipStream_t s, int phase)
@@ -92,8 +92,12 @@ int run_bwd_ds(const fa::BwdParams& pq, int grid_q, const fa::BwdParams& pk, int
 
 int ds_phase()
 {
+#if defined(FA_BWD_EXPERIMENTS)         // only in experiment builds (tools/exp_bwd_overlap.py): the shipped library ignores the variable
     const char* e = std::getenv("FA_MI355_BWD_PHASE");
     return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+#else
+    return 0;
+#endif
 }
 
 template <class T, int D>

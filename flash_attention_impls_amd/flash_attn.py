@@ -264,7 +264,7 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     return o, lse
 
 
-_ds_refused: set = set()        # (device, bytes) of hand-off workspaces the allocator has refused: not asked for again
+_ds_refused: dict = {}          # (device, bytes) of hand-off workspaces the allocator has refused -> calls left before it is asked again
 _plan_cache: dict = {}          # (shape, environment switches) -> (batches per launch, hand-off bytes or 0, recompute bytes)
 
 
@@ -312,13 +312,19 @@ def _bwd_plan(lib, dims, device):
                     big = 0
             if not 0 < big <= cap:
                 bc, hc, big = B, H, 0
+        if len(_plan_cache) >= 4096:        # (a bound, not a policy: shapes seen by one process are few)
+            _plan_cache.clear()
         sizes = _plan_cache[key] = (bc, hc, big, lib.fa_bwd_ex_workspace_bytes(*dims))
     bc, hc, big, small = sizes
-    if big and (device, big) not in _ds_refused:
-        try:
-            return bc, hc, torch.empty(big, dtype=torch.uint8, device=device), big
-        except torch.cuda.OutOfMemoryError:
-            _ds_refused.add((device, big))
+    if big:
+        wait = _ds_refused.get((device, big), 0)
+        if wait > 0:                        # refused a moment ago: the recompute path for the next calls, then one more try
+            _ds_refused[(device, big)] = wait - 1
+        else:
+            try:
+                return bc, hc, torch.empty(big, dtype=torch.uint8, device=device), big
+            except torch.cuda.OutOfMemoryError:
+                _ds_refused[(device, big)] = 64
     return B, H, torch.empty(small, dtype=torch.uint8, device=device), small
 
 

@@ -1,6 +1,7 @@
 """Experiment: overlap the HBM-bound dQ GEMM of batch chunk c with the matrix-bound dK/dV kernel of chunk c+1 on a second stream
 (the two cannot share a CU, so any gain comes from the GEMM needing fewer CUs than the whole chip to saturate HBM).
-Uses the library's experiment switch FA_MI355_BWD_PHASE (1 = pre-pass + dK/dV kernel, 2 = dQ GEMM alone)."""
+Needs an experiment build of the library: bash tools/build_variant.sh exp -DFA_BWD_EXPERIMENTS, whose switch
+FA_MI355_BWD_PHASE selects 1 = pre-pass + dK/dV kernel, 2 = dQ GEMM alone (the shipped library ignores the variable)."""
 import importlib
 import os
 import sys
@@ -11,7 +12,7 @@ import torch
 fmod = importlib.import_module("flash_attention_impls_amd.flash_attn")
 from flash_attention_impls_amd.bench_utils import attn_flops
 
-lib = fmod.load_library()
+lib = fmod.load_library(os.path.join("build", "libexp.so"))
 B, H, S, D, causal = 8, 32, 4096, 128, True
 torch.manual_seed(0)
 q, k, v, do = (torch.randn(B, H, S, D, device="cuda").to(torch.bfloat16) for _ in range(4))
