@@ -10,6 +10,8 @@ python bench.py --workload cfg3nc --no-cpu-baseline > $O/bench_cfg3nc.json 2> $O
 python bench.py --workload cfg2 --no-cpu-baseline > $O/bench_cfg2.json 2> $O/bench_cfg2.err &&
 python bench.py --mode fwdbwd --no-cpu-baseline > $O/bench_fwdbwd.json 2> $O/bench_fwdbwd.err &&
 timeout -k 10 600 python tools/report_all.py > $O/all_configs.txt 2> $O/all_configs.err &&
+timeout -k 10 300 python tools/bench_bwd.py --configs cfg2,cfg3,cfg3nc,cfg3fp16,cfg4,ref-bwd,d64,ref-main > $O/bwd_bench.txt 2> $O/bwd_bench.err &&
+(bash tools/build_variant.sh recompute -DFA_BWD_DS_DISABLE > /dev/null 2>&1; timeout -k 10 400 python tools/sweep_bwd_handoff.py > $O/bwd_handoff_sweep.txt 2>&1; true) &&
 timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --rehearse-gather --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err &&
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-dist --dist-backend nccl --steps 10 --warmup 3 --no-cpu-baseline --no-attainable > $O/bench_n1_nccl.json 2> $O/bench_n1_nccl.err
 echo rc=$?
