@@ -194,8 +194,8 @@ size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
  * dK/dV kernel writes the 16-bit dS it forms to the workspace and dQ = scale * dS . K becomes one streaming GEMM over it
  * (flash_attention_impls_amd/csrc/fa_bwd_dq_gemm_kernel.hpp), instead of a second kernel that recomputes S, P, dP and dS.
  * HBM capacity and bandwidth for matrix work: cfg3 causal backward 3.67 -> 3.26 ms (profiles/r3_bwd_handoff_sweep.txt).
- * dQ, dK and dV have been bitwise those of the recompute path on every shape measured (both form the same 16-bit dS and sum
- * dS . K in the same key order); the tests assert bitwise equality for dK and dV and the stated tolerance for dQ.
+ * dQ, dK and dV are bitwise those of the recompute path (both form the same 16-bit dS and sum dS . K in the same key order;
+ * asserted on a shape grid, on randomly drawn extended shapes and on cfg3 at full size: tests/test_bwd_ds_gpu.py).
  * Deterministic, no atomics.  One head's image may be of any size (both kernels address it through descriptors of two slab
  * rows); a caller short of memory splits the call over batches or over groups of query heads and reuses one workspace.
  * Returns 0 where the hand-off cannot pay (head_dim <= 64 with a dS image of more than 256 MiB: the bytes moved do not
