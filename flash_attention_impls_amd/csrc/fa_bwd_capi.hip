@@ -237,6 +237,19 @@ size_t fa_bwd_ex_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D
     return ((stats_bytes(B, H, S_q) + 255) / 256) * 256 + 2 * partial_bytes(B, H_kv, gp * qp, S_k, D);
 }
 
+#if defined(FA_BWD_STAMP)
+// diagnostic build (tools/stamps_bwd.py): read (and clear) the dK/dV kernel's stamp sums
+int fa_debug_read_bwd_stamps(void* dst, size_t bytes, int clear)
+{
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(fa::g_fa_bwd_stamp), bytes, 0, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && clear) {
+        static const unsigned long long zeros[64] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(fa::g_fa_bwd_stamp), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice);
+    }
+    return (int)e;
+}
+#endif
+
 size_t fa_bwd_ds_workspace_bytes(int B, int H, int H_kv, int S_q, int S_k, int D)
 {
 #if defined(FA_BWD_DKDV_SINGLE)

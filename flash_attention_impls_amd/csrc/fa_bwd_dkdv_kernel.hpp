@@ -27,6 +27,25 @@
 
 namespace fa {
 
+#if defined(FA_BWD_STAMP)
+// Diagnostic build only (-DFA_BWD_STAMP; never shipped, never timed; tools/stamps_bwd.py reads it): per-wave cycle sums by
+// s_memtime stamps, added up over all workgroups of a launch: [wave][0] whole kernel, [1] DMA wait of a step, [2] the step's
+// barrier, [3] staging issue behind it, [4] the step's work (scores + softmax, or the gradient products), [5] steps,
+// [6] prologue of a head pass (first tiles, their wait, the barrier).  The stamps drain the LDS reads the real kernel keeps in
+// flight across steps: read the SHARES, not the lengths.
+__device__ unsigned long long g_fa_bwd_stamp[8][8];
+__device__ __forceinline__ unsigned long long bwd_stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define FA_BWD_ST(...) __VA_ARGS__
+#else
+#define FA_BWD_ST(...)
+#endif
+
 constexpr int kDkdvStages = 3;
 template <int D> constexpr int dkdv_lds_bytes() { return 2 * kDkdvStages * kBN * D * 2 + kDkdvStages * 1024 + 2 * 4 * 4096; }
 
@@ -62,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     const int lane = tid & 63;
     const int li = lane & 15;
     const int lg = lane >> 4;
+    FA_BWD_ST(unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_t0 = bwd_stamp_now(); unsigned long long st_last = st_t0;)
 
     int head, xb;                              // key blocks in launch order: heaviest (first) first under the causal mask
     if (!wg_decode(blockIdx.x, p.bh, p.nxb, p.hsplit, head, xb)) return;
@@ -180,13 +200,17 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
     // which nothing here waits for)
     auto open_step = [&] __device__ (auto st_c, auto half_c, int i, auto waits_c, auto role_c) {
         constexpr int ST = decltype(st_c)::value, HALF = decltype(half_c)::value;
+        FA_BWD_ST(unsigned long long t_ = bwd_stamp_now(); st_sum[4] += t_ - st_last; st_last = t_; st_sum[5] += 1;)      // the previous step's work
         if constexpr (HALF == 1 && decltype(waits_c)::value) dma_wait<0>();      // tile i/2 + 1 (issued a tile ago) has landed
+        FA_BWD_ST(t_ = bwd_stamp_now(); st_sum[1] += t_ - st_last; st_last = t_;)
 #if !defined(FA_BWD_ABL_NOBAR)     // timing-only build without the barrier
         __syncthreads();                                          // publishes the mailbox of block i-1 (and tile i/2 + 1), retires block i-2
 #endif
+        FA_BWD_ST(t_ = bwd_stamp_now(); st_sum[2] += t_ - st_last; st_last = t_;)
         if constexpr (HALF == 1) {
             if ((i >> 1) + 2 < j_end) issue_tile((i >> 1) + 2, IC<(ST + 2) % NS>{}, role_c);
         }
+        FA_BWD_ST(t_ = bwd_stamp_now(); st_sum[3] += t_ - st_last; st_last = t_;)
     };
     // one trip = one turn of the ring (6 blocks); step i = 2 j_end only drains the gradient waves.  The two roles run
     // separate loops (separate register sets) with the same sequence of barriers: one in the prologue (tile j_begin
@@ -206,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
         issue_tile(j_begin + 1, IC<1>{}, role_c);
         if constexpr (NDMA == NW || decltype(role_c)::value == 1) dma_wait<OPS>();                                          // tile j_begin has landed (tile j_begin + 1 stays in flight)
         __syncthreads();
+        FA_BWD_ST({ const unsigned long long t_ = bwd_stamp_now(); st_sum[6] += t_ - st_last; st_last = t_; })
         prologue(g);
         for (int i = 2 * j_begin; i <= 2 * j_end; i += 2 * NS) {
             body(IC<0>{}, IC<0>{}, i);
@@ -215,7 +240,13 @@ __global__ __launch_bounds__(512, 2) void fa_bwd_dkdv_kernel(const BwdParams p)
             if (i + 4 <= 2 * j_end) body(IC<2>{}, IC<0>{}, i + 4);
             if (i + 5 <= 2 * j_end) body(IC<2>{}, IC<1>{}, i + 5);
         }
+        FA_BWD_ST({ const unsigned long long t_ = bwd_stamp_now(); st_sum[4] += t_ - st_last; st_last = t_; })
       }
+#if defined(FA_BWD_STAMP)
+      st_sum[0] = bwd_stamp_now() - st_t0;          // (before the epilogue's stores)
+      if (lane == 0)
+          for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_fa_bwd_stamp[wave][k_], st_sum[k_]);
+#endif
     };
 
     if (role == 0) {
