@@ -107,8 +107,9 @@ def _declare(lib):
     lib.fa_fwd_fp8_ex.argtypes = lib.fa_fwd_fp8.argtypes[:5] + [c.c_int] * 6 + lib.fa_fwd_fp8.argtypes[9:]
     lib.fa_bwd_ex_workspace_bytes.restype = c.c_size_t
     lib.fa_bwd_ex_workspace_bytes.argtypes = [c.c_int] * 6
-    lib.fa_bwd_ds_workspace_bytes.restype = c.c_size_t
-    lib.fa_bwd_ds_workspace_bytes.argtypes = [c.c_int] * 6
+    if hasattr(lib, "fa_bwd_ds_workspace_bytes"):      # (FA_VERSION >= 133; A/B arms built from older sources lack it: recompute path)
+        lib.fa_bwd_ds_workspace_bytes.restype = c.c_size_t
+        lib.fa_bwd_ds_workspace_bytes.argtypes = [c.c_int] * 6
     lib.fa_bwd_ex.restype = c.c_int
     lib.fa_bwd_ex.argtypes = lib.fa_bwd.argtypes[:9] + [c.c_int] * 6 + lib.fa_bwd.argtypes[13:]
     lib.fa_fwd_dispatch.restype = c.c_int
@@ -290,7 +291,7 @@ def _bwd_plan(lib, dims, device):
     sizes = _plan_cache.get(key)
     if sizes is None:                       # (the size rules are pure functions of the shape: asked once per shape, not per call)
         bc, hc, big = B, H, 0
-        if key[1] != "0":
+        if key[1] != "0" and hasattr(lib, "fa_bwd_ds_workspace_bytes"):
             cap = float(key[2]) * 2 ** 30
             big = lib.fa_bwd_ds_workspace_bytes(*dims)
             if big > cap:
