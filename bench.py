@@ -481,7 +481,7 @@ def main():
             # the backward's dS hand-off moves bytes on purpose: 2 x the bytes of the visible part of S per head,
             # written once by the dK/dV kernel and read once by the dQ GEMM, in exchange for two matrix products
             ds = 2.0 * B * H * S * S * 2 * (0.5 if causal else 1.0)
-            need = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D)
+            need = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D) if hasattr(lib, "fa_bwd_ds_workspace_bytes") else 0
             taken = need > 0 and os.environ.get("FA_MI355_BWD_DS", "1") != "0" and \
                 need <= float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30
             out["roofline"]["handoff"] = {"taken": bool(taken), "dS_bytes_written_plus_read": ds if taken else 0.0,
