@@ -56,6 +56,9 @@ WORKLOADS = {
     "cfg5": dict(B=8, H=32, S=4096, D=128, dtype="fp8", causal=False),
 }
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp8": torch.float8_e4m3fn}
+# --scaling strong: batches of the ONE problem that is split over the ranks (cfg3 8/W batches, cfg4 16/W heads,
+# cfg5 64/W batches per rank); the other workloads split their per-GPU shape
+STRONG_TOTAL_B = {"cfg5": 64}
 
 
 def parse():
@@ -84,6 +87,11 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (RCCL with one rank is a valid communicator): "
                          "runs init_process_group, the barriers and the gather timings for real on a one-GPU box")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, what the driver runs): every rank owns the workload's per-GPU shard (8 batches), total work "
+                         "grows with N.  strong: SURVEY 8(e)'s split of ONE fixed problem -- cfg3 8 batches, cfg4 16 heads, cfg5 64 "
+                         "batches -- into contiguous (batch x head) units per rank (flash_attention_impls_amd.dist.shard_bounds); "
+                         "`value` = the whole problem's FLOPs / the slowest rank's time")
     ap.add_argument("--no-attainable", action="store_true", help="skip the MFMA-only ceiling measurement")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples")
     return ap.parse_args()
@@ -317,6 +325,14 @@ def main():
 
     w = WORKLOADS[args.workload]
     B, H, S, D, causal = w["B"], w["H"], w["S"], w["D"], w["causal"]
+    strong = args.scaling == "strong"
+    total_B, total_H = STRONG_TOTAL_B.get(args.workload, B) if strong else B * world, H
+    if strong:
+        # this rank's contiguous slice of the B_total x H independent (batch, head) units, held as ONE batch of `hi - lo` heads
+        # (a unit is a whole attention problem; the kernels' grid mapping only sees the product B x H anyway)
+        from flash_attention_impls_amd.dist import shard_bounds
+        lo, hi = shard_bounds(total_B * total_H, rank, world)
+        B, H = 1, hi - lo
     dt = DT[w["dtype"]]
     torch.manual_seed(0 + rank)
     descale = None
@@ -425,12 +441,38 @@ def main():
     kt = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)) if args.steps > 0 else [float("nan")]
     kernel_ms = sum(kt) / len(kt)
 
+    peak_memory = None
+    if fwdbwd and rank == 0:
+        # peak device memory of ONE forward + backward step (FA2-triton.py:349 prints max_memory_allocated for its run): with the
+        # workspace the plan chose, and -- for comparison -- on the recompute path (FA_MI355_BWD_DS=0), after the timed region
+        def peak_of_step():
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            base = torch.cuda.memory_allocated(dev)
+            step()
+            torch.cuda.synchronize()
+            return base, torch.cuda.max_memory_allocated(dev)
+        base, pk = peak_of_step()
+        prev = os.environ.get("FA_MI355_BWD_DS")
+        os.environ["FA_MI355_BWD_DS"] = "0"
+        try:
+            _, pk0 = peak_of_step()
+        finally:
+            if prev is None:
+                os.environ.pop("FA_MI355_BWD_DS", None)
+            else:
+                os.environ["FA_MI355_BWD_DS"] = prev
+        peak_memory = {"resident_before_step_GiB": base / 2 ** 30, "step_peak_GiB": pk / 2 ** 30,
+                       "step_peak_recompute_GiB": pk0 / 2 ** 30, "handoff_transient_GiB": (pk - pk0) / 2 ** 30,
+                       "note": "torch.cuda.max_memory_allocated over one forward + backward step; the difference is the dS hand-off "
+                               "workspace (2 S_q S_k bytes per query head, capped by FA_MI355_BWD_DS_MAX_GIB)"}
     flops_rank = attn_flops(B, H, S, D, causal) * (3.5 if fwdbwd else 1.0)
     bytes_rank = attn_bytes(B, H, S, D, in_bytes=1 if w["dtype"] == "fp8" else 2)
     if fwdbwd:      # backward: q, k, v, o, dO and the LSE read once, dq, dk, dv written once
         bytes_rank += 8.0 * B * H * S * D * 2 + B * H * S * 4
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
-    value = world * flops_rank / (elapsed / max(args.steps, 1)) / 1e12
+    flops_job = attn_flops(total_B, total_H, S, D, causal) * (3.5 if fwdbwd else 1.0) if strong else world * flops_rank
+    value = flops_job / (elapsed / max(args.steps, 1)) / 1e12
     if w["dtype"] == "fp8":
         peak, compute_dtype = fp8_peak(lib)
     else:
@@ -442,7 +484,10 @@ def main():
         # after the timed region and outside `value`: a failure here (a collective the backend lacks, memory) must not cost
         # the run its bench line -- but it must be collective-safe, so every rank takes the same path and reports its error
         try:
-            gather = time_gather(dist, fa, q, k, v, causal, descale, world, args.gather_chunks, barrier, dev, backend)
+            if strong and (total_B * total_H) % world != 0:
+                gather = {"skipped": "ragged shards (units not a multiple of the world size): flash_attn_sharded pads them, this timing does not"}
+            else:
+                gather = time_gather(dist, fa, q, k, v, causal, descale, world, args.gather_chunks, barrier, dev, backend)
         except Exception as e:  # noqa: BLE001
             gather = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -451,12 +496,16 @@ def main():
         out = {
             "metric": "attn_fwdbwd_tflops" if fwdbwd else "attn_fwd_tflops", "value": value, "unit": "TFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": compute_dtype, "input_dtype": w["dtype"], "data": "synthetic",
-            "config": {"workload": f"{args.workload}: B={B} H={H} S={S} D={D} {w['dtype']} "
-                                   f"{'causal' if causal else 'non-causal'} per GPU" +
+            "config": {"workload": (f"{args.workload}: B={total_B} H={total_H} S={S} D={D} {w['dtype']} "
+                                    f"{'causal' if causal else 'non-causal'} in all, {total_B * total_H} (batch, head) units split over {world} rank(s): "
+                                    f"rank 0 holds {H}" if strong else
+                                    f"{args.workload}: B={B} H={H} S={S} D={D} {w['dtype']} "
+                                    f"{'causal' if causal else 'non-causal'} per GPU") +
                                    (" (BASELINE.json metric config)" if args.workload == "cfg3" else " (not the metric config: that is cfg3)"),
                        "B_per_gpu": B, "H": H, "S": S, "D": D, "causal": causal,
+                       "B_total": total_B, "units_total": total_B * total_H, "units_rank0": B * H,
                        "sharding": f"batch x head units split over {world} rank(s), no data-path collective",
                        "flops_rule": "4*B*H*S^2*D, halved when causal (FA2 convention)" +
                                      (" x 3.5 (forward + five backward products / two)" if fwdbwd else ""),
@@ -481,10 +530,12 @@ def main():
             # the backward's dS hand-off moves bytes on purpose: 2 x the bytes of the visible part of S per head,
             # written once by the dK/dV kernel and read once by the dQ GEMM, in exchange for two matrix products
             ds = 2.0 * B * H * S * S * 2 * (0.5 if causal else 1.0)
-            need = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D) if hasattr(lib, "fa_bwd_ds_workspace_bytes") else 0
-            taken = need > 0 and os.environ.get("FA_MI355_BWD_DS", "1") != "0" and \
-                need <= float(os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16")) * 2 ** 30
+            from flash_attention_impls_amd.flash_attn import bwd_plan_info
+            plan = bwd_plan_info((B, H, S, D), (B, H, S, D), dev)          # what the step above really ran (chunks included)
+            taken = plan["handoff"]
+            out["peak_memory"] = peak_memory
             out["roofline"]["handoff"] = {"taken": bool(taken), "dS_bytes_written_plus_read": ds if taken else 0.0,
+                                          "launch_sets": plan["chunks"], "workspace_bytes": plan["workspace_bytes"],
                                           "note": "deliberate traffic beyond the algorithmic bytes: the dS hand-off (5 matrix products "
                                                   "instead of 7); FA_MI355_BWD_DS=0 selects the recompute backward"}
         if rehearsal:

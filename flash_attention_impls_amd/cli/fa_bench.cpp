@@ -118,6 +118,26 @@ int main(int argc, char** argv)
     printf("%-25s %10.2f GB/s\n", "Flash Throughput:", bytes / (ms * 1e-3) / 1e9);
     printf("%-25s %10.3f GFLOPs/s  (%.1f %% of the dense 16-bit MFMA peak)\n", "Flash Compute:", flops / (ms * 1e-3) / 1e9,
            100.0 * flops / (ms * 1e-3) / 2516.6e12);
+    // what back-to-back MFMAs of this type deliver on THIS device (fa_diag_mfma_loop on the Q tensor's data: the matrix cores run
+    // against the board's power limit, not against the clock the nominal peak assumes) -- bench.py's roofline.attainable
+    {
+        float* sink = nullptr;
+        if (hipMalloc(&sink, 16) == hipSuccess && n * 2 >= 65536) {
+            double mf = 0.0;
+            const int iters = 2000;
+            for (int i = 0; i < 200; ++i) fa_diag_mfma_loop(dtype, iters, Q, sink, &mf, nullptr);      // ~0.4 s: the clock settles under the load
+            HIP_OK(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < 20; ++i) fa_diag_mfma_loop(dtype, iters, Q, sink, &mf, nullptr);
+            HIP_OK(hipEventRecord(e1, nullptr));
+            HIP_OK(hipEventSynchronize(e1));
+            float ms2 = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms2, e0, e1));
+            const double att = mf / (ms2 / 20 * 1e-3);
+            printf("%-25s %10.3f GFLOPs/s  attainable by bare MFMAs on this device and data (%.2f of the nominal peak): the kernel reaches %.2f of it\n",
+                   "MFMA ceiling:", att / 1e9, att / 2516.6e12, flops / (ms * 1e-3) / att);
+            hipFree(sink);
+        }
+    }
     hipFree(Q); hipFree(K); hipFree(V); hipFree(O); hipFree(lse);
     return pass ? 0 : 1;
 }

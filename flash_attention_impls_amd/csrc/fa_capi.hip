@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/fa_mi355.h"
 #include "fa_capi_common.hpp"
@@ -133,7 +134,7 @@ template <class T, int D>
 int launch_c(const fa::FwdParams& p, int grid, bool causal, int bm, hipStream_t s)
 {
 #if !defined(FA_MFMA32)
-    if constexpr (kQB == 1 && D == 64) {
+    if constexpr (kQB == 1) {
         if (bm == 128) return causal ? launch_rows128<T, D, true>(p, grid, s) : launch_rows128<T, D, false>(p, grid, s);
     }
 #endif
@@ -197,6 +198,11 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
 bool unpaired_for(int B, int H, int S, bool causal, int bm = fa::kBM)
 {
     const long long nqb = (S + bm - 1) / bm;
+#if defined(FA_FWD_EXPERIMENTS)         // experiment builds only (tools/build_variant.sh ... -DFA_FWD_EXPERIMENTS): FA_MI355_FORCE_UNPAIRED=0/1 overrides the estimate
+    if (const char* e = std::getenv("FA_MI355_FORCE_UNPAIRED")) {
+        if (e[0] == '0' || e[0] == '1') return causal && nqb > 1 && e[0] == '1';
+    }
+#endif
     return causal && fa_capi::causal_unpaired((long long)B * H, nqb, fa_capi::device_cus());
 }
 
@@ -229,9 +235,19 @@ int rows_per_wg(int B, int H, int S, int D, bool causal)
     (void)B; (void)H; (void)S; (void)D; (void)causal;
     return fa::kBM;
 #else
-    if (D > 64 || S <= 128) return fa::kBM;
+    if (S <= 128) return fa::kBM;
+#if defined(FA_FWD_EXPERIMENTS)         // experiment builds only: FA_MI355_ROWS=128/256 overrides the rule
+    if (const char* e = std::getenv("FA_MI355_ROWS")) {
+        if (e[0] == '1') return 128;
+        if (e[0] == '2') return fa::kBM;
+    }
+#endif
     const int g = grid_for(B, H, S, causal);
-    return (g > 0 && 4 * g <= 3 * fa_capi::device_cus()) ? 128 : fa::kBM;
+    if (D <= 64) return (g > 0 && 4 * g <= 3 * fa_capi::device_cus()) ? 128 : fa::kBM;
+    // head_dim 128 (round 4: the few-head shards of a strong split, e.g. 2 of cfg4's 16 heads per GPU): 128-row workgroups of the
+    // 32x32x16 kernel (4 waves, one per SIMD) once the 256-row grid leaves at least half of the CUs without a workgroup -- a lone
+    // wave per SIMD runs a tile at ~0.6 of a pair's rate, so the chip must at least double its busy CUs for that to pay
+    return (g > 0 && 2 * g <= fa_capi::device_cus()) ? 128 : fa::kBM;
 #endif
 }
 

@@ -1,5 +1,6 @@
 // Shared by the C-ABI translation units: per-thread error message and stride decoding.
 #pragma once
+#include "fa_build_guard.hpp"      // first: it looks at the switches the command line set, before any header defines defaults
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>

@@ -67,6 +67,8 @@ extern "C" {
 
 int fa_device_cus(void) { return fa_capi::device_cus(); }
 
+int fa_build_is_default(void) { return FA_BUILD_NON_DEFAULT ? 0 : 1; }
+
 int fa_diag_mfma_loop(int dtype, int iters, const void* operands, float* sink, double* flops_out, void* stream)
 {
     fa_capi::g_err[0] = 0;

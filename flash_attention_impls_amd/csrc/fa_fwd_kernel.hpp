@@ -26,6 +26,7 @@
 //   * exp2 with scale*log2(e) folded in, deferred 1/l normalisation, causal block skipping + diagonal-only
 //     masking, LSE output.
 #pragma once
+#include "fa_build_guard.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -209,13 +210,6 @@ __device__ __forceinline__ u32x2 lds_read_tr16_b64(unsigned addr) {
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                  :: "v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
-}
-// The same with a wave-uniform byte offset in the instruction's scalar-offset field: address = base + voff + soff, the range
-// check sees voff alone -- for tiles known to lie inside the buffer (the unrolled steady loop), where it saves the per-piece
-// vector add of the tile offset; `voff` beyond the descriptor still reads zeros (the head_dim padding chunks)
-__device__ __forceinline__ void dma16s(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
 }
 // wait until at most N of this wave's DMA instructions are still in flight (vmcnt counts in issue order)
 template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }

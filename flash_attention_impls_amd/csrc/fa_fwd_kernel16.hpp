@@ -37,33 +37,8 @@
 #ifndef FA_CONT_EARLY_Q
 #define FA_CONT_EARLY_Q 1
 #endif
-// FA_PP: "ping-pong" main loop at head_dim 128 (see the PP branch of the kernel): the two waves of a SIMD alternate a
-// matrix-only phase with a load / softmax phase, one barrier per phase.  Experiment; results are
-// bitwise those of the default loop.
-#ifndef FA_S_CHAIN
-#define FA_S_CHAIN 0
-#endif
 #ifndef FA_HALF_PRIO
 #define FA_HALF_PRIO 1
-#endif
-#ifndef FA_PP
-#define FA_PP 0
-#endif
-#ifndef FA_PP_PRIO
-#define FA_PP_PRIO 0
-#endif
-#ifndef FA_PP_ORDER
-#define FA_PP_ORDER 1
-#endif
-#ifndef FA_PP_M32
-#define FA_PP_M32 0
-#endif
-#ifndef FA_PP_DMA_IN_C
-#define FA_PP_DMA_IN_C 0
-#endif
-// FA_DMA_SOFF: in the unrolled steady loop the tile offset of a staging DMA rides in the instruction's scalar offset
-#ifndef FA_DMA_SOFF
-#define FA_DMA_SOFF 0
 #endif
 
 namespace fa {
@@ -117,7 +92,6 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     // pipelined inside a wave (S(n), softmax(n), P V(n) in program order: one S^T and one P^T register set instead of two --
     // the pipelined form needs ~134 registers and spilled), the other three waves of the SIMD fill the gaps
     constexpr bool LEAN = DD == 64;
-    constexpr bool PP = FA_PP && DD == 128 && !QK8;
     constexpr int QKB = QK8 ? 1 : 2;           // bytes per Q / K element
     constexpr int KROWB = D * QKB;             // bytes per K row in LDS
     constexpr int CPTK = kBN * KROWB / 1024 / NWAVES;   // K DMA pieces per wave per tile (2, fp8: 1)
@@ -152,14 +126,6 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int wg_per_head = paired ? (p.nqb + 1) / 2 : p.nqb;
     int head, tq;
     if (!wg_decode(blockIdx.x, p.bh, wg_per_head, p.hsplit, head, tq)) return;
-#if defined(FA_STAGGER)
-    // experiment: the workgroups of the first dispatch round start FA_STAGGER x 64 cycles apart (8 steps by slot), so that
-    // the equal-length workgroups that follow on each CU do not run their prologues (an HBM burst) all at the same moment
-    if (blockIdx.x < 256) {
-        const int st = (blockIdx.x >> 3) & 7;
-        for (int i = 0; i < st; ++i) __builtin_amdgcn_s_sleep(FA_STAGGER);
-    }
-#endif
     const int b = head / p.H;
     const int h = head - b * p.H;
     const int S = p.S;                         // query rows
@@ -279,12 +245,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         const int stage_j = ST < 0 ? stage_k : ST;
         if constexpr (I < CPTK) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(kpiece_base + ((stage_j + 3) & (kStages - 1)) * TILE + I * PIECE);
-            if constexpr (ST >= 0 && FA_DMA_SOFF) dma16s(rk_w, dst, g_koff[I], (unsigned)(j + 3) * k_tile_stride);
-            else dma16(rk_w, dst, (unsigned)(ST >= 0 ? j + 3 : tk(j + 3)) * k_tile_stride + g_koff[I]);
+            dma16(rk_w, dst, (unsigned)(ST >= 0 ? j + 3 : tk(j + 3)) * k_tile_stride + g_koff[I]);
         } else if constexpr (I < CPTK + CPT) {
             const unsigned dst = __builtin_amdgcn_readfirstlane(piece_base + VBASE + ((stage_j + 2) & (kStages - 1)) * TILE + (I - CPTK) * PIECE);
-            if constexpr (ST >= 0 && FA_DMA_SOFF) dma16s(rv_w, dst, g_voff[I - CPTK], (unsigned)(j + 2) * v_tile_stride);
-            else dma16(rv_w, dst, (unsigned)(ST >= 0 ? j + 2 : tk(j + 2)) * v_tile_stride + g_voff[I - CPTK]);
+            dma16(rv_w, dst, (unsigned)(ST >= 0 ? j + 2 : tk(j + 2)) * v_tile_stride + g_voff[I - CPTK]);
         }
     };
 
@@ -419,21 +383,12 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             return;
         }
 #endif
-#if FA_S_CHAIN          // experiment: the four k-steps of one accumulator back to back (a dependent chain), then the other query tile
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                if constexpr (QK8) s_acc[par][kt][qt] = mfma16_fp8(kf8[ks], qf8[qt][ks], s_acc[par][kt][qt]);
-                else s_acc[par][kt][qt] = T::mfma16(kf[ks], qf[qt][ks], s_acc[par][kt][qt]);
-#else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
                 if constexpr (QK8) s_acc[par][kt][qt] = mfma16_fp8(kf8[ks], qf8[qt][ks], s_acc[par][kt][qt]);
                 else s_acc[par][kt][qt] = T::mfma16(kf[ks], qf[qt][ks], s_acc[par][kt][qt]);
-#endif
     };
     auto advance = [&](int dk, int dv) {
 #pragma unroll
@@ -703,176 +658,6 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             sync_and_stage(j);
             end_iter();
         }
-    } else if constexpr (PP) {
-        // ---- ping-pong loop.  Per 32-key block n a wave runs two phases, each closed by a workgroup barrier:
-        //   C(n): the 16 MFMAs of S(n) = K(n) Q^T and the 16 of O^T += V^T(n-1) P^T(n-1) -- operands all in registers, nothing
-        //         else in the stream;
-        //   L(n): softmax(n) -> P(n); V^T fragments of block n and K fragments of block n + 1 read from LDS; this wave's two
-        //         staging DMA pieces (K(j + 3) behind an even block of tile j, V(j + 2) behind an odd one); counted DMA wait.
-        // Waves 4..7 (the SIMD partners of 0..3) run ONE phase behind: whenever a wave is in a C phase its partner is in an L
-        // phase, so the matrix pipe always has exactly one client per SIMD and the vector port serves the MFMAs of one wave
-        // and the softmax of the other.  Nothing is pipelined inside a wave: one S^T, one P^T register set.
-        const int NT = my_nt;
-        const int mbl = min(CAUSAL ? (max(0, q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block that needs the mask
-        u32x4 kfa[2][KS];          // K fragments of one block [key tile][k-step]
-        u32x4 vfa[DT];             // V^T fragments of one block [head_dim tile]
-        auto rd_k = [&] __device__ (auto half_c) {
-            constexpr int half = decltype(half_c)::value;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kfa[kt][ks] = lds_read_b128(ka[ks] + (32 * half + 16 * kt) * KROWB);
-        };
-        auto rd_v = [&] __device__ (auto half_c) {
-            constexpr int half = decltype(half_c)::value;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                u32x2 lo = lds_read_tr16_b64(va[dt] + (32 * half) * ROWB);
-                u32x2 hi = lds_read_tr16_b64(va[dt] + (32 * half + 16) * ROWB);
-                vfa[dt] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
-        };
-        auto c_phase = [&] __device__ (bool do_s, bool do_pv, int dma_kind, int jj) {
-#if FA_PP_DMA_IN_C      // the two staging pieces of the L phase in front are issued here instead, in front of the MFMAs
-            if (dma_kind == 1) dma_k(tk(jj + 3), ((stage_k + 3) & (kStages - 1)) * TILE);
-            else if (dma_kind == 2) dma_v(tk(jj + 2), ((stage_k + 1) & (kStages - 1)) * TILE);   // (stage_k: tile jj + 1)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#if FA_PP_PRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#if FA_PP_M32       // timing only (wrong results): the same products on 32x32x16 MFMAs -- half as many instructions, each holding
-                    // the vector port 8 of its 32 cycles -- fed with the same operand registers
-            typedef __attribute__((ext_vector_type(16))) float f32x16;
-            if (do_s) {
-                f32x16 a;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) a[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8>(kfa[kt][ks]), bitcast<bf16x8>(qf[kt][ks]), a, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s_acc[0][(i >> 3) & 1][(i >> 2) & 1][i & 3] = a[i];
-            }
-            if (do_pv) {
-#pragma unroll
-                for (int g = 0; g < DT / 2; ++g) {
-                    f32x16 a;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) a[i] = o_acc[2 * g + (i >> 3)][(i >> 2) & 1][i & 3];
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8>(vfa[2 * g]), bitcast<bf16x8>(pf[0][0]), a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bitcast<bf16x8>(vfa[2 * g + 1]), bitcast<bf16x8>(pf[0][1]), a, 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o_acc[2 * g + (i >> 3)][(i >> 2) & 1][i & 3] = a[i];
-                }
-            }
-#else
-            if (do_s) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) s_acc[0][kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int qt = 0; qt < 2; ++qt) s_acc[0][kt][qt] = T::mfma16(kfa[kt][ks], qf[qt][ks], s_acc[0][kt][qt]);
-            }
-            if (do_pv) {
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = T::mfma16(vfa[dt], pf[0][qt], o_acc[dt][qt]);
-            }
-#endif
-#if FA_PP_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            __syncthreads();
-        };
-        auto softmax_blk = [&] __device__ (auto first_c, int n) {
-            constexpr bool FIRST = decltype(first_c)::value;
-            const int key0 = n * 32;
-            if (n >= mbl) {
-                if constexpr (FIRST) sm_set_reference(Y{}, IC<0>{}, key0);
-                sm_slice(Y{}, IC<0>{}, IC<0>{}, IC<0>{}, key0);
-                sm_slice(Y{}, IC<0>{}, IC<0>{}, IC<1>{}, key0);
-                sm_slice(Y{}, IC<0>{}, IC<1>{}, IC<0>{}, key0);
-                sm_slice(Y{}, IC<0>{}, IC<1>{}, IC<1>{}, key0);
-            } else {
-                if constexpr (FIRST) sm_set_reference(N{}, IC<0>{}, key0);
-                sm_slice(N{}, IC<0>{}, IC<0>{}, IC<0>{}, key0);
-                sm_slice(N{}, IC<0>{}, IC<0>{}, IC<1>{}, key0);
-                sm_slice(N{}, IC<0>{}, IC<1>{}, IC<0>{}, key0);
-                sm_slice(N{}, IC<0>{}, IC<1>{}, IC<1>{}, key0);
-            }
-        };
-        const bool late = wave >= 4;               // (waves w and w + 4 share a SIMD)
-        if (late) __syncthreads();
-        if (NT > 0) rd_k(IC<0>{});                 // phase L(-1)
-        __syncthreads();
-        for (int j = 0; j < nt; ++j) {
-            const bool act = j < NT;
-            // block 2j  (FA_PP_DMA_IN_C: V(j + 1), the pieces of the previous odd L phase)
-            c_phase(act, j > 0 && j <= NT, j > 0 ? 2 : 0, j - 1);
-#if FA_PP_ORDER == 1     // fragment reads and the DMA pieces first (they travel under the softmax), then the softmax
-            if (act) {
-                rd_v(IC<0>{});
-                rd_k(IC<1>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#if !FA_PP_DMA_IN_C
-            dma_k(tk(j + 3), ((stage_k + 3) & (kStages - 1)) * TILE);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            if (act) {
-                if (j == 0) softmax_blk(Y{}, 0); else softmax_blk(N{}, 2 * j);
-            }
-#else
-            if (act) {
-                if (j == 0) softmax_blk(Y{}, 0); else softmax_blk(N{}, 2 * j);
-                rd_v(IC<0>{});
-                rd_k(IC<1>{});
-            }
-            dma_k(tk(j + 3), ((stage_k + 3) & (kStages - 1)) * TILE);
-#endif
-            dma_wait<FA_PP_DMA_IN_C ? CPT : CPTK + CPT>();
-            __syncthreads();
-            // block 2j + 1  (FA_PP_DMA_IN_C: K(j + 3))
-            c_phase(act, act, 1, j);
-#if FA_PP_ORDER == 1
-            if (act) {
-                rd_v(IC<1>{});
-                const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
-                advance(d, d);
-                if (j + 1 < NT) rd_k(IC<0>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#if !FA_PP_DMA_IN_C
-            dma_v(tk(j + 2), ((stage_k + 2) & (kStages - 1)) * TILE);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            if (act) softmax_blk(N{}, 2 * j + 1);
-#else
-            if (act) {
-                softmax_blk(N{}, 2 * j + 1);
-                rd_v(IC<1>{});
-                const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
-                advance(d, d);
-                if (j + 1 < NT) rd_k(IC<0>{});
-            }
-            dma_v(tk(j + 2), ((stage_k + 2) & (kStages - 1)) * TILE);
-#endif
-            dma_wait<FA_PP_DMA_IN_C ? CPT : CPTK + CPT>();
-            __syncthreads();
-            end_iter();
-        }
-        if (FA_CONT_EARLY_Q && cont) load_q(tq, lane_here());
-        c_phase(false, NT == nt && NT > 0, 2, nt - 1);  // the last P V product of the waves that compute on every tile
-        if (!late) __syncthreads();
     } else {
     const int NT = my_nt;                          // 64-key tiles this wave computes on
     const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 5) : 0x7fffffff, Sk >> 5);   // first block whose softmax needs the mask
@@ -1201,6 +986,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         unsigned long long st_rt1;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1) :: "memory");
         d[0] = st_e; d[1] = st_w; d[2] = st_o; d[3] = st_n; d[4] = stamp_now() - st_t0; d[5] = st_rt1 - st_rt0;
+        // where and when the workgroup ran (tools/stamps.py: gaps between consecutive workgroups of a CU, spread of their end times):
+        // absolute start in s_memrealtime ticks (100 MHz, one counter for the chip), XCC_ID and HW_ID (shader engine / array / CU)
+        d[6] = st_rt0;
+        d[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #pragma unroll
         for (int i = 0; i < 12; ++i) d[8 + i] = st_ph[i];
     }

@@ -51,6 +51,22 @@ constexpr float kPRefTop8 = 8.0f;
 constexpr float kGapFloor8 = 12.0f;            // a score further than this below mx counts as mx - 12 in the mean (one very low key must not move the window)
 constexpr float kSumFloor8 = 0.92f;            // WANT_LSE: rounded row sum below this share of the exact one -> exact fallback (underflowed weight)
 constexpr float kPLimit8 = 1e30f;              // a rounded row sum not below this (i.e. NaN: some P left e4m3's range) -> exact fallback
+// !WANT_LSE (no exact sums to compare with): a SAMPLED bound on the weight e4m3 cannot hold.  Behind a row's first 128-key block
+// (whose keys the window was placed by) one score in 32 -- one element of one key tile per block, another one in odd blocks: 4 of
+// a row's 128 keys -- adds min(P, 2^-9) to a per-lane sum u; 2^-9 is e4m3's smallest subnormal: everything below it is rounded to
+// 0 or up to it.  32 u estimates U = sum over the keys of min(P, 2^-9) >= the weight below the window.  Ordinary rows have
+// U <= 0.5 % of the row sum L (2^-9 over the mean P, which the window places at 2^-2 ... 2^1); a row whose tail sits under the
+// window has U ~ the tail's whole weight.  32 u > L / 64 sends the workgroup to the exact loop, as the rounded-vs-exact
+// comparison does where the exact sums exist.  Why so sparse a sample suffices: a full first block makes L >= 128 x 2^-2 (the mean
+// score sits 2 binades under the top of the window or higher), so a tail that carries 5 % of L under the window is > 1600 keys:
+// > 50 samples.  Cost: 4 of ~190 vector instructions per wave and block (measured: -0.6 %; one score in eight: -2.2 %).
+#ifndef FA8_SAMPLED_CHECK
+#define FA8_SAMPLED_CHECK_ON 1
+#else
+#define FA8_SAMPLED_CHECK_ON FA8_SAMPLED_CHECK
+#endif
+constexpr float kUnderCap8 = 0.001953125f;     // 2^-9
+constexpr float kSampleGain8 = 32.0f * 64.0f;  // sampling rate x inverse trigger share
 
 // 16-byte-chunk swizzles of the 128-byte rows (two rows per 256-byte bank row)
 //  K, read by rows (ds_read_b128, chunks g and g + 4 of row i): chunk ^ ((row >> 1) & 7)
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     const i32x8 ones8 = {0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838, 0x38383838};   // e4m3 1.0
     float m_c[2] = {-INFINITY, -INFINITY};
     float l_a[2] = {0.f, 0.f}, l_b[2] = {0.f, 0.f};    // this lane's share of the exact row sums (LSE): two add chains per query tile
+    float u_s[2] = {0.f, 0.f};                         // !WANT_LSE: this lane's sampled sum of min(P, 2^-9) (kUnderCap8 above)
     const float c = p.scale_log2;
 
     // mask: key (relative to the lane's first key 4 g of a tile) is dead iff it exceeds limq - (first key of the tile); the
@@ -237,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     f32x4 s_acc[2][2];         // S^T tiles [slot = key tile parity][query tile]
     i32x8 pf[2][2];            // P^T fragments [block parity][query tile], dword kt
 
-    auto sm_slice = [&] __device__ (auto mask_c, auto par_c, auto kt_c, int key0) {
-        constexpr bool MASK = decltype(mask_c)::value;
+    auto sm_slice = [&] __device__ (auto mask_c, auto par_c, auto kt_c, auto samp_c, int key0) {
+        constexpr bool MASK = decltype(mask_c)::value, SAMP = decltype(samp_c)::value;
         constexpr int par = decltype(par_c)::value, kt = decltype(kt_c)::value;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -254,6 +271,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[2], c, -m_c[qt]));
             const float p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[3], c, -m_c[qt]));
             if constexpr (WANT_LSE) { l_a[qt] += p0; l_b[qt] += p1; l_a[qt] += p2; l_b[qt] += p3; }
+            else if constexpr (FA8_SAMPLED_CHECK_ON != 0 && SAMP && kt == (par == 0 ? 2 : 5)) {
+                u_s[qt] += __builtin_fminf(par == 0 ? p1 : p2, kUnderCap8);      // (with the buffer parity: another element of another key tile)
+            }
             // (both halves of the word are overwritten: its old content serves as the conversions' pass-through operand,
             // which saves the v_mov a fresh zero would cost.)  A P beyond e4m3's range (> 464) converts to NaN.
             pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, pf[par][qt][kt], false), true);
@@ -411,10 +431,9 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
                 read_v(IC<(R + 1) & 7>{}, IC<R & 1>{});
             }
             if constexpr (R == 0) {
-                if constexpr (SL0) sm_slice(mask_c, IC<PAR ^ 1>{}, IC<7>{}, key0 - kBN8);
+                if constexpr (SL0) sm_slice(mask_c, IC<PAR ^ 1>{}, IC<7>{}, std::false_type{}, key0 - kBN8);
             } else if constexpr (SL) {
-                (void)FIRST;
-                sm_slice(mask_c, IC<PAR>{}, IC<R - 1>{}, key0);
+                sm_slice(mask_c, IC<PAR>{}, IC<R - 1>{}, std::integral_constant<bool, !FIRST>{}, key0);      // (the first block is not sampled)
             }
 #if !defined(FA8_NO_SGB)
             if constexpr (DO_S && PV && SL && SL0) {       // steady form: 4 x {1 MFMA, DS reads, 5 VALU}
@@ -524,6 +543,15 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             le += __shfl_xor(le, 16);
             le += __shfl_xor(le, 32);
             bad_row = bad_row || (l_acc[qt][0] < kSumFloor8 * le);
+        }
+    } else if constexpr (FA8_SAMPLED_CHECK_ON != 0) {
+        // ... and where they do not: the sampled bound on the weight under the window (kUnderCap8 above)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float u = u_s[qt];
+            u += __shfl_xor(u, 16);
+            u += __shfl_xor(u, 32);
+            bad_row = bad_row || (l_acc[qt][0] < kSampleGain8 * u);
         }
     }
     if (wg_any(bad_row, lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {

@@ -118,6 +118,9 @@ def _declare(lib):
     lib.fa_fwd_launch_info.restype = c.c_int
     lib.fa_fwd_launch_info.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int,
                                        c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    if hasattr(lib, "fa_build_is_default"):    # (FA_VERSION >= 134)
+        lib.fa_build_is_default.restype = c.c_int
+        lib.fa_build_is_default.argtypes = []
     if hasattr(lib, "fa_diag_mfma_loop"):      # (diagnostics, FA_VERSION >= 132; A/B arms built from older sources lack them)
         lib.fa_device_cus.restype = c.c_int
         lib.fa_device_cus.argtypes = []
@@ -265,8 +268,9 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
     return o, lse
 
 
-_ds_refused: dict = {}          # (device, bytes) of hand-off workspaces the allocator has refused -> calls left before it is asked again
-_plan_cache: dict = {}          # (shape, environment switches) -> (batches per launch, hand-off bytes or 0, recompute bytes)
+_ds_refused: dict = {}          # (device index, bytes) of hand-off workspaces that did not fit -> [calls left before the next look, current back-off]
+_plan_cache: dict = {}          # (shape, device, CU count, environment switches) -> (batches per launch, heads per launch, hand-off bytes or 0, recompute bytes)
+_ws_poison = False              # test hook (tests/test_bwd_ds_gpu.py): fill every backward workspace with 0xFF before it is used
 
 
 def _equal_parts(n: int, fit: int) -> int:
@@ -274,25 +278,42 @@ def _equal_parts(n: int, fit: int) -> int:
     return -(-n // -(-n // fit))
 
 
+def _ds_fits(device, nbytes: int) -> bool:
+    """Can the hand-off workspace be had WITHOUT pushing the caching allocator into an out-of-memory retry (which frees every
+    cached block: device synchronisations and hipFree calls, a stall of a training step near its memory limit)?  Yes if the
+    allocator already holds that much unused (reserved - allocated: the block of the previous call, typically), else if the
+    driver reports that much free plus a margin.  The driver query costs about a launch: it only runs when the cache has no
+    room, i.e. on the first call of a shape and after the block was given up."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx) >= nbytes:
+        return True
+    free, _total = torch.cuda.mem_get_info(idx)
+    return free >= nbytes + (256 << 20)
+
+
 def _bwd_plan(lib, dims, device):
     """How one backward runs: ``(batches per launch, query heads per launch, workspace, its size)``.
 
     The dS hand-off (include/fa_mi355.h: fa_bwd_ds_workspace_bytes -- 2 S_q S_k bytes per query head on top of the row
-    statistics) is taken where the library says it qualifies and pays.  Its workspace is kept under
-    FA_MI355_BWD_DS_MAX_GIB (default 16 of the 288 GB): a launch that needs more is split into equal chunks that run one after
-    the other through the same workspace -- whole batches first; where one batch alone does not fit (long sequences: 16 heads
-    at S = 32768 are 32 GiB), groups of query heads that share a key/value head.  (batch, head) slices are independent, and a
-    chunk of several GiB of dS is a launch of milliseconds.  If not even one group fits, the allocator cannot provide the
-    workspace, or FA_MI355_BWD_DS=0: the recompute path's small workspace and one launch.  (No driver query on the way:
-    hipMemGetInfo costs as much as a launch; the caching allocator hands the same block back call after call.)"""
+    statistics) is taken where the library says it qualifies and pays.  It is a TRANSIENT allocation at the point of the
+    backward where activations are largest: 8 GiB at (8,32,4096,128), kept under FA_MI355_BWD_DS_MAX_GIB (default 16 of the
+    288 GB): a launch that needs more is split into equal chunks that run one after the other through the same workspace --
+    whole batches first; where one batch alone does not fit (long sequences: 16 heads at S = 32768 are 32 GiB), groups of
+    query heads that share a key/value head.  (batch, head) slices are independent, and a chunk of several GiB of dS is a
+    launch of milliseconds.  If not even one group fits, FA_MI355_BWD_DS=0, or the memory is not there (`_ds_fits`: decided
+    from the allocator's own figures, never by provoking an out-of-memory retry; looked at again after 1, 2, 4 ... 1024
+    calls): the recompute path's small workspace and one launch.  The size rules are pure functions of the shape, the device
+    and its CU count: computed once per (shape, device)."""
     B, H, Hkv = dims[0], dims[1], dims[2]
-    key = (dims, os.environ.get("FA_MI355_BWD_DS", "1"), os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16"),
+    dev_idx = device.index if device.index is not None else torch.cuda.current_device()
+    cus = lib.fa_device_cus() if hasattr(lib, "fa_device_cus") else 256          # (of the current device: the caller runs under _on_device)
+    key = (dims, dev_idx, cus, os.environ.get("FA_MI355_BWD_DS", "1"), os.environ.get("FA_MI355_BWD_DS_MAX_GIB", "16"),
            os.environ.get("FA_MI355_BWD_DS_MIN_BLOCKS_PER_CU", "2"))
     sizes = _plan_cache.get(key)
-    if sizes is None:                       # (the size rules are pure functions of the shape: asked once per shape, not per call)
+    if sizes is None:
         bc, hc, big = B, H, 0
-        if key[1] != "0" and hasattr(lib, "fa_bwd_ds_workspace_bytes"):
-            cap = float(key[2]) * 2 ** 30
+        if key[3] != "0" and hasattr(lib, "fa_bwd_ds_workspace_bytes"):
+            cap = float(key[4]) * 2 ** 30
             big = lib.fa_bwd_ds_workspace_bytes(*dims)
             if big > cap:
                 per = lib.fa_bwd_ds_workspace_bytes(1, *dims[1:])
@@ -306,8 +327,7 @@ def _bwd_plan(lib, dims, device):
                     big = lib.fa_bwd_ds_workspace_bytes(1, hc, groups, *dims[3:])
                     # a chunk must still fill the chip: with fewer than two 256-row query blocks per CU the launches of a chunk run
                     # half empty and the split costs more than the hand-off gains ((1,8,65536,128) head by head: -1.4 %)
-                    cus = lib.fa_device_cus() if hasattr(lib, "fa_device_cus") else 256
-                    if hc * ((dims[3] + 255) // 256) < float(key[3]) * cus:
+                    if hc * ((dims[3] + 255) // 256) < float(key[5]) * cus:
                         big = 0
                 else:
                     big = 0
@@ -317,16 +337,46 @@ def _bwd_plan(lib, dims, device):
             _plan_cache.clear()
         sizes = _plan_cache[key] = (bc, hc, big, lib.fa_bwd_ex_workspace_bytes(*dims))
     bc, hc, big, small = sizes
+    ws = None
     if big:
-        wait = _ds_refused.get((device, big), 0)
-        if wait > 0:                        # refused a moment ago: the recompute path for the next calls, then one more try
-            _ds_refused[(device, big)] = wait - 1
+        state = _ds_refused.get((dev_idx, big))
+        if state is not None and state[0] > 0:      # did not fit a moment ago: the recompute path for the next calls, then one more look
+            state[0] -= 1
         else:
-            try:
-                return bc, hc, torch.empty(big, dtype=torch.uint8, device=device), big
-            except torch.cuda.OutOfMemoryError:
-                _ds_refused[(device, big)] = 64
-    return B, H, torch.empty(small, dtype=torch.uint8, device=device), small
+            ok = _ds_fits(device, big)
+            if ok:
+                try:
+                    ws = torch.empty(big, dtype=torch.uint8, device=device)
+                except torch.cuda.OutOfMemoryError:          # (fragmentation: the figures said yes, the allocator could not)
+                    ok = False
+            if ok:
+                _ds_refused.pop((dev_idx, big), None)
+            else:
+                back = min(1024, 2 * state[1]) if state is not None else 1
+                _ds_refused[(dev_idx, big)] = [back, back]
+    if ws is None:
+        bc, hc, big = B, H, 0
+        ws = torch.empty(small, dtype=torch.uint8, device=device)
+    if _ws_poison:
+        ws.fill_(0xFF)
+    return bc, hc, ws, big or small
+
+
+def bwd_plan_info(q_shape, kv_shape, device=None) -> dict:
+    """What `_bwd_plan` decides for a backward of these (B, H, N, D) / (B, H_kv, N_k, D) shapes on `device` right now (bench.py's
+    `roofline.handoff`, tools/report_all.py): {"handoff": bool, "chunks": launches, "workspace_bytes": transient allocation,
+    "ds_bytes_full": the hand-off image of the whole launch or 0 where the library declines it}."""
+    lib = load_library()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    B, H, N, D = q_shape
+    Hkv, Nk = kv_shape[1], kv_shape[2]
+    dims = (B, H, Hkv, N, Nk, D)
+    with _on_device(device):
+        bc, hc, ws, nbytes = _bwd_plan(lib, dims, device)
+        full = lib.fa_bwd_ds_workspace_bytes(*dims) if hasattr(lib, "fa_bwd_ds_workspace_bytes") else 0
+    small = lib.fa_bwd_ex_workspace_bytes(*dims)
+    del ws
+    return {"handoff": nbytes > small, "chunks": -(-B // bc) * -(-H // hc), "workspace_bytes": int(nbytes), "ds_bytes_full": int(full)}
 
 
 def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
@@ -395,9 +445,9 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     reference).  ``return_lse=True`` additionally returns the (B, H, N) fp32 natural
     log-sum-exp of the scaled scores (the reference keeps m and l instead: lse = m + ln l).
     ``descale`` = (q, k, v) per-tensor dequantisation scales of float8_e4m3fn inputs (rejected for other dtypes).
-    ``fp8_checked=True`` (float8 inputs): run the kernel variant that forms the exact row sums even when no LSE is asked for, so
-    that weight lost below e4m3's range is noticed and the rows redone exactly (include/fa_mi355.h, fa_fwd_fp8: the one input
-    class the default variant cannot notice -- a row whose first 128 keys ALL stand far above a heavy tail); costs a few per cent.
+    float8 inputs: every kernel variant notices softmax weight lost below e4m3's range and redoes those rows exactly
+    (include/fa_mi355.h, fa_fwd_fp8) -- the default one through a sampled bound (one score in 32), the one that returns the
+    LSE through its exact row sums.  ``fp8_checked=True`` runs the exact-sum variant even when no LSE is asked for (~4 % slower).
     Differentiable like the reference's entry point: when autograd is recording and an input requires
     grad, the HIP backward kernels produce dq, dk, dv (bf16 / fp16 / fp32-via-fp16 inputs).
     """

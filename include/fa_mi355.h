@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 133          /* 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
+#define FA_VERSION 134          /* 0.1.34: fp8 forward without LSE checks the whole row (sampled bound), fa_build_is_default; 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -100,11 +100,17 @@ int fa_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
  * scale, the v scale into the output.  No reference counterpart (the reference is fp16 only); BASELINE.json
  * config 5.  Stated accuracy for fp8 inputs: relative Frobenius error <= 5 %.
  *   Where P sits in e4m3's range is chosen per row from the scores of its FIRST 128 KEYS (reference = their maximum; window
- *   opened downwards by how far the rest of the sample lies below it).  Known limitation: a row whose first 128 keys are ALL
- *   far above a tail that still carries a large share of the softmax weight (> 9 binades below them) loses that tail to e4m3's
- *   underflow.  With lse != NULL the kernel forms the exact row sums anyway, notices that the rounded sum falls short
- *   (< 0.92 of the exact one) and redoes the workgroup with its exact running-maximum loop; with lse == NULL there is nothing
- *   to compare with and the loss is silent: a caller that cannot rule such inputs out passes an LSE buffer (cost ~4 %).
+ *   opened downwards by how far the rest of the sample lies below it).  No finite sample can see a tail that lies under the
+ *   window behind a first block that is dominant as a whole, so every variant checks the WHOLE row and redoes a workgroup
+ *   whose rows lost weight with its exact running-maximum loop (results then as accurate as on ordinary data):
+ *     lse != NULL: the exact fp32 row sums exist anyway; a rounded row sum under 0.92 of the exact one triggers the redo;
+ *     lse == NULL: (the default of the Python entry) behind the first block one score in 32 adds min(P, 2^-9) to a sampled
+ *                  bound on the weight below e4m3's smallest subnormal; an estimate above 1/64 of the row sum triggers the
+ *                  redo (ordinary rows stay under 1/200; a heavy tail under the window IS that weight, and must be > 1600
+ *                  keys long to matter).  Cost: < 1 % of the kernel.
+ *   The stated 5 % bound holds for both (tests/test_cfg5_gpu.py: first block dominant as a whole at S = 4096, 32768, 65536
+ *   with 8 - 55 % of each row's weight in the tail; tests/golden/fp8_d128_block0_dominant_*.npz from the reference's own
+ *   sdpa_reference).
  *   strides are in elements (= bytes) with unit head_dim stride; rows and bases 16-byte aligned.
  *   workspace: device buffer of at least fa_fp8_workspace_bytes(B,H,S,D) bytes, 16-byte aligned (0 bytes for
  *              head_dim > 64: the pointer may then be NULL; three bf16 tensors otherwise).
@@ -132,6 +138,8 @@ int fa_fwd_fp8(const void* q, const void* k, const void* v, void* o, float* lse,
  *                       (bench.py: `roofline.attainable`).
  */
 int fa_device_cus(void);
+/* 1 if this library was compiled from the sources with no experiment / ablation / diagnostic switch set (csrc/fa_build_guard.hpp). */
+int fa_build_is_default(void);
 int fa_diag_mfma_loop(int dtype, int iters, const void* operands, float* sink, double* flops_out, void* stream);
 
 /*

@@ -47,6 +47,17 @@ def golden_names():
     return [n for n in _all_golden() if not n.startswith(("bwd_", "gqa_", "kvlen_"))]
 
 
+def golden_rows(d, a):
+    """The rows of a (B, H, S, ...) array that a fixture stores outputs for: all of them, or -- large fixtures, whose "o" / "lse"
+    hold every 64th row only -- the ones listed in its "rows" entry."""
+    return a[:, :, d["rows"]] if "rows" in d else a
+
+
+def golden_small_names():
+    """Forward fixtures small enough for the slow restatements (the pure-Python tile loop, the scalar C oracle)."""
+    return [n for n in golden_names() if "block0_dominant" not in n]
+
+
 def golden_bwd_names():
     """Backward fixtures (q,k,v,do,o,lse,delta,dq,dk,dv)."""
     return [n for n in _all_golden() if n.startswith("bwd_")]

@@ -37,8 +37,12 @@ def inputs(B, H, Hkv, Sq, Sk, D, dtype, seed):
 
 
 def grads(q, k, v, do, causal, monkeypatch, ds: bool):
-    """(dq, dk, dv) through the library's own workspace choice, with the hand-off allowed or not."""
+    """(dq, dk, dv) through the library's own workspace choice, with the hand-off allowed or not.  EVERY workspace is filled
+    with 0xFF (a NaN pattern in both 16-bit types and in fp32) before the launch (flash_attn._ws_poison): a dS unit, a partial sum
+    or a statistics row that is read without having been written in THIS call cannot hide behind the identical stale image the
+    caching allocator hands back from the previous call."""
     monkeypatch.setenv("FA_MI355_BWD_DS", "1" if ds else "0")
+    monkeypatch.setattr(fmod, "_ws_poison", True)
     lib = fa.load_library()
     scale = q.shape[-1] ** -0.5
     o, lse = fmod._fwd_raw(lib, q, k, v, causal, scale, None, True)
@@ -239,3 +243,38 @@ def test_full_size_cfg3_handoff(monkeypatch):
     for (b, h) in ((0, 0), (7, 31), (3, 17)):
         ref = orc.naive_attention_bwd_f64(*[t[b:b + 1, h:h + 1].float().cpu().numpy() for t in (q, k, v, do)], causal=True)
         check_against_oracle(dq1[b:b + 1, h:h + 1], ref[0], "bf16", f"dq[{b},{h}]")
+
+
+def test_workspace_cap_bounds_the_transient_memory(monkeypatch):
+    """the dS hand-off is a transient allocation on top of the step's tensors, and FA_MI355_BWD_DS_MAX_GIB bounds
+    it: torch.cuda.max_memory_allocated over one forward + backward step with the default cap (the whole image: 2 S_q S_k bytes
+    per query head), with a cap under the image (equal batch chunks through a smaller workspace) and with the hand-off off."""
+    B, H, S, D = 4, 8, 2048, 128
+    q, k, v, do = inputs(B, H, H, S, S, D, torch.bfloat16, seed=31)
+    lib = fa.load_library()
+    image = lib.fa_bwd_ds_workspace_bytes(B, H, H, S, S, D)
+    small = lib.fa_bwd_ex_workspace_bytes(B, H, H, S, S, D)
+    assert image >= 2 * B * H * S * S
+
+    def peak(env):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        leaves = [t.clone().requires_grad_(True) for t in (q, k, v)]
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        fa.flash_attn(*leaves, True).backward(do)
+        torch.cuda.synchronize()
+        return torch.cuda.max_memory_allocated() - base, [t.grad for t in leaves]
+
+    full, g_full = peak({"FA_MI355_BWD_DS": "1", "FA_MI355_BWD_DS_MAX_GIB": "16"})
+    capped, g_cap = peak({"FA_MI355_BWD_DS": "1", "FA_MI355_BWD_DS_MAX_GIB": repr(0.3 * image / 2 ** 30)})      # one batch per chunk
+    off, g_off = peak({"FA_MI355_BWD_DS": "0"})
+    assert full - off >= 0.9 * (image - small), (full, off, image)                  # the image is what the hand-off adds ...
+    assert capped - off <= 0.3 * image + (8 << 20), (capped, off, image)            # ... and the cap bounds it
+    assert capped < full
+    for a, b_, c in zip(g_full, g_cap, g_off):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16)) and torch.equal(a.view(torch.int16), c.view(torch.int16))
+    info = fmod.bwd_plan_info((B, H, S, D), (B, H, S, D), q.device)                   # (environment: hand-off off)
+    assert info["handoff"] is False and info["chunks"] == 1 and info["ds_bytes_full"] == image

@@ -137,3 +137,33 @@ def test_rccl_path_at_world_size_one():
     res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_rehearsal_worker.py"), "--backend", "nccl"])
     assert res.returncode == 0 and "DIST_REHEARSAL_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
+def test_bench_strong_scaling_over_rccl_at_world_size_one():
+    """`bench.py --scaling strong` (ONE problem split into contiguous (batch, head) units per rank -- cfg3 8/W
+    batches, cfg4 16/W heads, cfg5 64/W batches) under torch.distributed.run over nccl at world size 1: the whole problem is rank
+    0's shard, `value` counts the whole problem's FLOPs, and the line says "strong"."""
+    res = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                "--settle-ms", "30", "--workload", "cfg4", "--scaling", "strong", "--no-cpu-baseline", "--no-attainable", "--no-power",
+                "--dist-backend", "nccl", "--force-dist"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["units_total"] == 16 and out["config"]["units_rank0"] == 16 and out["config"]["B_total"] == 1
+    assert "error" not in out["gather"], out["gather"]
+
+
+def test_strong_split_shards_are_the_unsharded_result():
+    """The shards `bench.py --scaling strong` times -- rank r's contiguous units held as (1, n_r, S, D) -- are bitwise the
+    corresponding heads of the unsharded launch, for every rank of a 2-, 4- and 8-way split of a (2, 8) problem."""
+    from flash_attention_impls_amd.dist import shard_bounds
+    B, H, S, D = 2, 8, 700, 128
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(B, H, S, D, generator=g).to(torch.bfloat16).cuda() for _ in range(3))
+    ref = fa.flash_attn(q, k, v, True).reshape(1, B * H, S, D)
+    qf, kf, vf = (t.reshape(1, B * H, S, D) for t in (q, k, v))
+    for world in (2, 4, 8):
+        for r in range(world):
+            lo, hi = shard_bounds(B * H, r, world)
+            assert torch.equal(fa.flash_attn(qf[:, lo:hi], kf[:, lo:hi], vf[:, lo:hi], True), ref[:, lo:hi])

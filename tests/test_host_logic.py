@@ -405,3 +405,27 @@ def test_graft_entry_checks_the_header_version_not_a_literal():
     with open(os.path.join(root, "__graft_entry__.py")) as f:
         src = f.read()
     assert "FA_VERSION" in src and not re.search(r"fa_version\(\)\s*==\s*\d", src)
+
+
+def test_default_build_sets_no_experiment_switch():
+    """the shipped library is compiled with none of the experiment / ablation / diagnostic switches of the
+    kernel sources (csrc/fa_build_guard.hpp lists them; a timing-only ablation does not even compile without -DFA_TIMING_ONLY),
+    and says so itself."""
+    from flash_attention_impls_amd import _build
+    assert not [f for f in _build.HIPCC_FLAGS if f.startswith("-DFA")], _build.HIPCC_FLAGS
+    lib = fa.load_library()
+    assert lib.fa_build_is_default() == 1
+    guard = open(os.path.join(os.path.dirname(_build.CSRC), "csrc", "fa_build_guard.hpp")).read()
+    import glob
+    import re
+    used = set()
+    for path in glob.glob(os.path.join(_build.CSRC, "*.h*")):
+        if path.endswith("fa_build_guard.hpp"):
+            continue
+        for m in re.finditer(r"^\s*#\s*(?:if|ifdef|ifndef|elif)\b(.*)$", open(path).read(), re.M):
+            used.update(re.findall(r"\b(FA8?_[A-Z0-9_]+)\b", m.group(1).split("//")[0]))
+    # macros that are not switches: values of the public header, include guards of defaults computed by the sources themselves
+    not_switches = {"FA_DTYPE_BF16", "FA_DTYPE_FP16", "FA_DTYPE_FP8_E4M3", "FA_VERSION", "FA_BUILD_NON_DEFAULT", "FA_BUILD_WRONG_RESULTS",
+                    "FA_PERSIST_ON", "FA8_SAMPLED_CHECK_ON", "FA_SYNC_STAGE", "FA_SYNC_STAGE_C", "FA_ODD_BLOCK", "FA_PHASE", "FA8_PHASE"}
+    missing = sorted(m for m in used - not_switches if m not in guard)
+    assert not missing, f"switches tested by the sources but unknown to fa_build_guard.hpp: {missing}"

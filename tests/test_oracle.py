@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import c_oracle_fwd, golden_f32, golden_names, golden_torch, load_golden
+from conftest import c_oracle_fwd, golden_f32, golden_names, golden_rows, golden_small_names, golden_torch, load_golden
 from oracle import attn_oracle as orc
 
 NAMES = golden_names()
@@ -46,7 +46,7 @@ def test_sdpa_oracle_matches_reference(name):
     if d["dtype"] == "fp8":
         q, k, v = [torch.from_numpy(x) for x in _inputs(d)]
         o = orc.sdpa_oracle(q, k, v, causal=bool(d["causal"]))
-        assert torch.equal(o, torch.from_numpy(d["o"]))
+        assert torch.equal(golden_rows(d, o), torch.from_numpy(d["o"]))
         return
     q, k, v = [golden_torch(d, n) for n in "qkv"]
     o = orc.sdpa_oracle(q, k, v, causal=bool(d["causal"]))
@@ -58,11 +58,12 @@ def test_naive_f64_matches_reference(name):
     d = load_golden(name)
     q, k, v = _inputs(d)
     o, lse = orc.naive_attention_f64(q, k, v, causal=bool(d["causal"]))
+    o, lse = golden_rows(d, o), golden_rows(d, lse)
     assert np.abs(o - _ref_o(d)).max() < 2e-5 * max(1.0, np.abs(_ref_o(d)).max())
     assert np.abs(lse - d["lse"]).max() < 1e-4
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", golden_small_names())
 @pytest.mark.parametrize("deferred", [False, True])
 def test_tiled_restatement_matches_reference(name, deferred):
     """_fwd_kernel restatement (reference arithmetic and the build's deferred arithmetic)."""
@@ -87,7 +88,7 @@ def test_tiled_restatement_matches_reference_kernel_stats(name):
     assert np.abs(d["o_kernel"].astype(np.float32) - o).max() < 2e-2 * max(1.0, np.abs(o).max())
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", golden_small_names())
 def test_c_oracle_matches_reference(name, oracle_clib):
     d = load_golden(name)
     q, k, v = _inputs(d)

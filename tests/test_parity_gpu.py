@@ -74,7 +74,7 @@ def test_golden_vectors_fp8(name):
     """fp8-e4m3fn Q/K/V with per-tensor scales (BASELINE config 5 dtype), both products on fp8 MFMAs.
     Stated tolerance: relative Frobenius error <= 5 %, element-wise FP8_TOL (P rounded to e4m3); the LSE
     comes from the unrounded P and keeps the 1e-3 bound."""
-    from conftest import FP8_REL_FRO, FP8_TOL
+    from conftest import FP8_REL_FRO, FP8_TOL, golden_rows
     d = load_golden(name)
     q, k, v = [golden_torch(d, n, "cuda") for n in "qkv"]
     assert q.dtype == torch.float8_e4m3fn
@@ -82,11 +82,15 @@ def test_golden_vectors_fp8(name):
     o, lse = fa.flash_attn(q, k, v, bool(d["causal"]), descale=ds, return_lse=True)
     assert o.dtype == torch.bfloat16 and o.shape == q.shape
     ref = d["o"].astype(np.float64)
-    of = o.float().cpu().numpy().astype(np.float64)
-    assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
-    assert_close(o, ref, FP8_TOL, name)
     lse_ref = d["lse"].astype(np.float64)
-    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+    # (large fixtures store every 64th row only: conftest.golden_rows)
+    for got in (o, fa.flash_attn(q, k, v, bool(d["causal"]), descale=ds)):      # with the exact row sums, and the default call without
+        of = golden_rows(d, got.float().cpu().numpy()).astype(np.float64)
+        assert np.linalg.norm(of - ref) <= FP8_REL_FRO * np.linalg.norm(ref)
+        assert np.abs(of - ref).max() <= FP8_TOL * max(1.0, np.abs(ref).max()), name
+    assert np.abs(golden_rows(d, lse.cpu().numpy()) - lse_ref).max() <= 1e-3 * max(1.0, np.abs(lse_ref).max())
+    if "block0_dominant" in name:                # the fixture really is the heavy-tail case (not a no-op for the check)
+        assert np.median(d["w_tail"]) > 0.05
 
 
 def test_fp8_strided_and_raw_capi():

@@ -1,6 +1,10 @@
 """All BASELINE.json single-GPU configurations with the reference harness' semantics
 (measure_latency: 10 warm-ups, 100 per-iteration event timings, mean/std/min; code/triton_fa2/FA2-triton.py:249-268,
-340-354): ms, TFLOP/s, % of the dense bf16 MFMA peak, algorithmic GB/s, tokens/s, peak memory, max|o - SDPA|.
+340-354): ms, TFLOP/s, % of the dense bf16 MFMA peak, algorithmic GB/s, tokens/s, peak memory, max|o - SDPA|;
+"step MB" / "step MB rc": peak device memory (torch.cuda.max_memory_allocated, which FA2-triton.py:349 prints for its run) of one
+forward + backward step with the dS hand-off the backward takes by default (a transient 2 S_q S_k bytes per query head, capped
+by FA_MI355_BWD_DS_MAX_GIB) and on the recompute path (FA_MI355_BWD_DS=0); first line: what back-to-back MFMAs deliver on this
+device (bench.py's `roofline.attainable`).
 Last column: the same launch replayed from a captured HIP graph (100 launches per replay, per-launch ms) -- what the
 kernel costs once the Python / ctypes call is out of the way; it matters for the small, launch-bound shapes."""
 import math
@@ -50,10 +54,45 @@ def graph_latency(fn, launches=100, replays=5):
     return best
 
 
+def step_peak_mb(q, k, v, causal):
+    """Peak device memory (MB, above what is resident before) of one forward + backward step: (default backward, recompute backward)."""
+    out = []
+    for env in ("1", "0"):
+        prev = os.environ.get("FA_MI355_BWD_DS")
+        os.environ["FA_MI355_BWD_DS"] = env
+        try:
+            leaves = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+            d_o = torch.ones_like(q)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            flash_attn(*leaves, causal).backward(d_o)
+            torch.cuda.synchronize()
+            out.append((torch.cuda.max_memory_allocated() - base) / 1e6)
+            del leaves, d_o
+        finally:
+            if prev is None:
+                os.environ.pop("FA_MI355_BWD_DS", None)
+            else:
+                os.environ["FA_MI355_BWD_DS"] = prev
+    return out
+
+
 def main():
     print(torch.cuda.get_device_name(0))
+    try:        # the matrix cores' measured ceiling on this device (bench.py's roofline.attainable)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("fa_bench_main", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        from flash_attention_impls_amd import load_library
+        for name in ("bf16", "fp8"):
+            att, _ = bench.attainable_mfma(load_library(), name, torch.device("cuda", 0))
+            print(f"attainable ({name} MFMAs back to back on N(0,1) operands, this device): {att:.0f} TFLOP/s = {att / (5033.2 if name == 'fp8' else 2516.6):.2f} of the nominal dense peak")
+    except Exception as e:  # noqa: BLE001
+        print(f"attainable: not measured ({e})")
     print(f"{'config':26s} {'shape':22s} {'dtype':13s} {'causal':6s} {'mean ms':>9s} {'std':>7s} {'min ms':>8s} "
-          f"{'TFLOP/s':>8s} {'%peak':>6s} {'GB/s':>7s} {'Mtok/s':>8s} {'peakMB':>8s} {'max|o-sdpa|':>11s} {'graph ms':>9s}", flush=True)
+          f"{'TFLOP/s':>8s} {'%peak':>6s} {'GB/s':>7s} {'Mtok/s':>8s} {'peakMB':>8s} {'max|o-sdpa|':>11s} {'graph ms':>9s} {'step MB':>8s} {'step MB rc':>10s}", flush=True)
     for name, B, H, S, D, dt, causal in CONFIGS:
         torch.manual_seed(0)
         f32 = [torch.randn(B, H, S, D, device="cuda") for _ in range(3)]
@@ -84,7 +123,8 @@ def main():
         peak = 5033.2 if (dt == torch.float8_e4m3fn and D > 64) else 2516.6
         print(f"{name:26s} {str((B, H, S, D)):22s} {str(dt)[6:]:13s} {str(causal):6s} {m['mean_ms']:9.4f} "
               f"{m['std_ms']:7.4f} {m['min_ms']:8.4f} {tf:8.1f} {100 * tf / peak:6.1f} {by / sec / 1e9:7.0f} "
-              f"{B * H * S / sec / 1e6:8.1f} {peak_mb:8.0f} {err:11.3e} {graph_ms:9.4f}", flush=True)
+              f"{B * H * S / sec / 1e6:8.1f} {peak_mb:8.0f} {err:11.3e} {graph_ms:9.4f} " +
+              ("       -          -" if dt == torch.float8_e4m3fn else "{:8.0f} {:10.0f}".format(*step_peak_mb(q, k, v, causal))), flush=True)
 
 
 if __name__ == "__main__":

@@ -46,6 +46,11 @@ assert rc == 0, rc
 f = buf.astype(np.float64)
 tiles = f[:, :, 3]
 ok = tiles > 0
+n_seen = int(ok.any(axis=1).sum())
+if n_seen < n_wg:          # persistent launch: fewer workgroups than grid slots, each walks n_wg / n_seen items (sums below are per WORKGROUP)
+    print(f"persistent launch: {n_seen} workgroups for {n_wg} grid slots ({n_wg / max(1, n_seen):.1f} items per workgroup; the sums below are per workgroup, i.e. over its items)")
+    buf, f, tiles, ok = buf[:n_seen], f[:n_seen], tiles[:n_seen], ok[:n_seen]
+    n_wg = n_seen
 print(f"workgroups {n_wg}, stamped tiles per wave: mean {tiles[ok].mean():.1f}")
 if a.dtype == "fp8":
     print("wave   regions 0-3   wait+barrier+DMA issue   regions 4-7   total   [cycles per 128-key block, mean over workgroups]")
@@ -92,3 +97,33 @@ for r in range(rounds):
 print("per wave, phases 0-7 in the order listed above (cycles per workgroup):")
 for w in range(8):
     print(f"  wave {w}: " + " | ".join(f"{ph[:, w, i].mean():8.0f}" for i in range(8)))
+
+# ---- per-CU timelines (absolute s_memrealtime starts, XCC_ID / HW_ID of each workgroup: d[6], d[7] of the stamp record)
+if f[:, 0, 6].max() > 0:
+    start = buf[:, :, 6].min(axis=1).astype(np.int64)                 # ticks of 10 ns
+    end = (buf[:, :, 6] + buf[:, :, 5]).max(axis=1).astype(np.int64)
+    ids = buf[:, 0, 7]
+    xcc = (ids >> np.uint64(32)).astype(np.int64) & 0xF
+    hw = ids.astype(np.int64) & 0xFFFFFFFF
+    cu_key = xcc * (1 << 16) + ((hw >> 8) & 0xF) + (((hw >> 12) & 0x1) << 4) + (((hw >> 13) & 0x7) << 5)     # (xcc, se, sh, cu)
+    t0 = start.min()
+    gaps, firsts, lasts, per_cu = [], [], [], []
+    for key in np.unique(cu_key):
+        m = np.where(cu_key == key)[0]
+        o_ = m[np.argsort(start[m])]
+        per_cu.append(len(o_))
+        firsts.append(start[o_[0]] - t0)
+        lasts.append(end[o_].max() - t0)
+        gaps += list(start[o_[1:]] - end[o_[:-1]])
+    gaps = np.array(gaps, dtype=np.float64) / 100.0                   # us
+    lasts = np.array(lasts, dtype=np.float64) / 100.0
+    firsts = np.array(firsts, dtype=np.float64) / 100.0
+    span = (end.max() - t0) / 100.0
+    print(f"per-CU timelines of the LAST launch: {len(per_cu)} CUs seen, workgroups per CU min / median / max {min(per_cu)} / {int(np.median(per_cu))} / {max(per_cu)}")
+    print(f"  first workgroup start -> last workgroup end: {span:.1f} us (event-timed launch: {wall_us:.1f} us: {wall_us - span:.1f} us outside any workgroup of the launch)")
+    print(f"  first start of a CU after the launch's first: median {np.median(firsts):.2f} us, max {firsts.max():.2f} us")
+    print(f"  gap between consecutive workgroups of a CU: median {np.median(gaps):.2f} us, mean {gaps.mean():.2f}, p90 {np.quantile(gaps, 0.9):.2f}, max {gaps.max():.2f}  (x {len(gaps) / len(per_cu):.1f} per CU = {gaps.sum() / len(per_cu):.1f} us per CU)")
+    print(f"  last end of a CU before the launch's last end: median {np.median(span - lasts):.1f} us, mean {(span - lasts).mean():.1f}, max {(span - lasts).max():.1f}  (the tail)")
+    life = (end - start) / 100.0
+    print(f"  workgroup lifetime: mean {life.mean():.1f} us, p10 {np.quantile(life, 0.1):.1f}, p90 {np.quantile(life, 0.9):.1f}; by XCC: " +
+          " ".join(f"{life[xcc == x].mean():.1f}" for x in np.unique(xcc)))
