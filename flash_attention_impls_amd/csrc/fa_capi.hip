@@ -82,6 +82,22 @@ int launch16(const fa::FwdParams& p, int grid, hipStream_t stream)
     return FA_OK;
 }
 
+// the same kernel with 128-row workgroups (4 waves, one per SIMD) at head_dim 128: bitwise the 8-wave form's output
+template <class T, bool CAUSAL>
+int launch16_rows128(const fa::FwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::lds_bytes<128>();
+    auto* kernel = &fa::fa_fwd_kernel16<T, CAUSAL, false, 128, 4>;
+    struct Tag {};
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_fwd_kernel16<T, CAUSAL, false, 128, 4>), dim3(grid), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
+}
+
 // head_dim > 64, fp8 Q and K read natively by fp8 MFMAs, V and O bf16 (fa_fwd_kernel16<TypeBF16, CAUSAL, true>)
 template <bool CAUSAL>
 int launch16_qk8(const fa::FwdParams& p, int grid, hipStream_t stream)
@@ -134,8 +150,15 @@ template <class T, int D>
 int launch_c(const fa::FwdParams& p, int grid, bool causal, int bm, hipStream_t s)
 {
 #if !defined(FA_MFMA32)
-    if constexpr (kQB == 1) {
+    if constexpr (kQB == 1 && D == 64) {
         if (bm == 128) return causal ? launch_rows128<T, D, true>(p, grid, s) : launch_rows128<T, D, false>(p, grid, s);
+    }
+    if constexpr (kQB == 1 && D == 128) {
+#if defined(FA_ROWS128_MFMA32)      // A/B arm: the 128-row form of the 32x32x16 kernel instead (other rounding than the 256-row launches)
+        if (bm == 128) return causal ? launch_rows128<T, D, true>(p, grid, s) : launch_rows128<T, D, false>(p, grid, s);
+#else
+        if (bm == 128) return causal ? launch16_rows128<T, true>(p, grid, s) : launch16_rows128<T, false>(p, grid, s);
+#endif
     }
 #endif
     (void)bm;
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(256) void fp8_to_bf16_kernel(const unsigned char* _
 
 // causal launches pair query blocks (nqb-1-t, t) per workgroup for equal work -- unless single blocks, longest first, are
 // expected to finish earlier (fa_capi::causal_unpaired: small grids, or a mostly empty last round of pairs)
-bool unpaired_for(int B, int H, int S, bool causal, int bm = fa::kBM)
+bool unpaired_for(int B, int H, int S, bool causal, int bm = fa::kBM, bool lone = false)
 {
     const long long nqb = (S + bm - 1) / bm;
 #if defined(FA_FWD_EXPERIMENTS)         // experiment builds only (tools/build_variant.sh ... -DFA_FWD_EXPERIMENTS): FA_MI355_FORCE_UNPAIRED=0/1 overrides the estimate
@@ -203,14 +226,14 @@ bool unpaired_for(int B, int H, int S, bool causal, int bm = fa::kBM)
         if (e[0] == '0' || e[0] == '1') return causal && nqb > 1 && e[0] == '1';
     }
 #endif
-    return causal && fa_capi::causal_unpaired((long long)B * H, nqb, fa_capi::device_cus());
+    return causal && fa_capi::causal_unpaired((long long)B * H, nqb, fa_capi::device_cus(), lone);
 }
 
-int grid_for(int B, int H, int S, bool causal, int bm = fa::kBM)
+int grid_for(int B, int H, int S, bool causal, int bm = fa::kBM, bool lone = false)
 {
     const long long bh = (long long)B * H;
     const long long nqb = (S + bm - 1) / bm;
-    const long long per_head = (causal && !unpaired_for(B, H, S, causal, bm)) ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
+    const long long per_head = (causal && !unpaired_for(B, H, S, causal, bm, lone)) ? (nqb + 1) / 2 : nqb;   // causal: one workgroup per pair of query blocks
     const long long g = fa_capi::grid_blocks(bh, per_head, fa_capi::head_split(bh, per_head));   // (virtual) heads padded to a multiple of 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
 }
@@ -281,7 +304,7 @@ int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* g
         return FA_OK;
     }
     const int bm = (dtype == FA_DTYPE_FP8_E4M3 && D > 64) ? fa::kBM : rows_per_wg(B, H, S, D, causal != 0);
-    if (grid) *grid = grid_for(B, H, S, causal != 0, bm);
+    if (grid) *grid = grid_for(B, H, S, causal != 0, bm, bm == 128 && D > 64);
     if (block) *block = bm == 128 ? 256 : kThreads;
     if (lds_bytes) *lds_bytes = (D > 64) ? fa::lds_bytes<128>() : fa::lds_bytes<64>();
     return FA_OK;
@@ -328,7 +351,8 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     const bool wide = D > 128;
     const int bm = wide ? fa::kBMW : rows_per_wg(B, H, S, D, causal != 0);
     p.nqb = (S + bm - 1) / bm;
-    p.unpaired = wide ? 1 : (unpaired_for(B, H, S, causal != 0, bm) ? 1 : 0);
+    const bool lone = bm == 128 && D > 64;           // 128-row form of the head_dim-128 kernel: one wave per SIMD
+    p.unpaired = wide ? 1 : (unpaired_for(B, H, S, causal != 0, bm, lone) ? 1 : 0);
     {
         const long long nqb_ = (S + bm - 1) / bm;
         p.hsplit = fa_capi::head_split((long long)B * H, (causal != 0 && !p.unpaired) ? (nqb_ + 1) / 2 : nqb_);
@@ -360,7 +384,7 @@ int fa_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
     p.scale_log2 = p.scale * 1.4426950408889634f;
     p.out_scale = dvv;
 
-    const int grid = wide ? grid_wide(B, H, S, nullptr) : grid_for(B, H, S, causal != 0, bm);
+    const int grid = wide ? grid_wide(B, H, S, nullptr) : grid_for(B, H, S, causal != 0, bm, lone);
     if (grid <= 0) return fail(FA_ERR_TOO_LARGE, "grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool c = causal != 0;

@@ -73,13 +73,16 @@ inline long long grid_blocks(long long heads, long long per_head, int hsplit)
 // first?  Pairs are perfectly balanced but quantised: G workgroups on `cus` CUs (256 on a whole MI355X) take ceil(G / cus) rounds of nb + 1 block
 // units.  Single blocks take about max(nb, total work / 256) with some slack for the greedy order.  Returns true when the
 // single-block launch is expected to finish first (small grids, and grids whose last round of pairs would be mostly empty).
-inline bool causal_unpaired(long long heads, long long nb, int cus = 256)
+// `lone_waves`: 128-row workgroups (one wave per SIMD; grids that do not fill the chip): there single blocks win at equal estimates
+// (round 4, tools/exp_rows.py: (1,2,16384,128) 602 against 575 TFLOP/s, (1,4,4096,128) 273 against 247; equal where pairs fill the chip).
+inline bool causal_unpaired(long long heads, long long nb, int cus = 256, bool lone_waves = false)
 {
     if (nb <= 1) return false;
     const long long pairs = heads * ((nb + 1) / 2);
     const double t_pair = (double)((pairs + cus - 1) / cus) * (double)(nb + 1);
     const double work = (double)heads * (double)nb * (double)(nb + 1) / 2.0;
     const double t_single = std::max((double)nb, 1.2 * work / (double)cus);
+    if (lone_waves) return t_single <= t_pair;
     return t_single < 0.85 * t_pair;                 // (measured: at equal estimates the pairs win, the greedy order is no LPT)
 }
 

@@ -75,14 +75,20 @@ template <int D> __device__ __forceinline__ int v_swz16d(int row, int ch) {
 
 // QK8: Q and K are fp8 (OCP e4m3) tensors (element strides = byte strides) and S^T = K Q^T runs on fp8 MFMAs; V (and
 // the P V product, O) stay 16-bit of type T.  The K tile then takes the first half of its ring stage (128-byte rows).
-template <class T, bool CAUSAL, bool QK8 = false, int DD = 128>
-__global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const FwdParams p)
+// NWV = waves per workgroup: 8 (256 query rows, two waves per SIMD), or 4 (128 query rows, one wave per SIMD: launches whose
+// 256-row grid would leave half of the CUs or more without a workgroup -- the few-head shards of a strong split; fa_capi.hip,
+// rows_per_wg).  A wave does exactly the same arithmetic on its 32 rows either way -- the two forms return bitwise the same
+// output -- and stages twice the pieces per tile in the 4-wave form.
+template <class T, bool CAUSAL, bool QK8 = false, int DD = 128, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV, DD == 64 ? 4 : (NWV == 4 ? 1 : 2)) void fa_fwd_kernel16(const FwdParams p)
 {
+    static_assert(NWV == 8 || (NWV == 4 && DD == 128 && !QK8), "128-row workgroups: head_dim 128, 16-bit Q / K only");
+    constexpr int BM = 32 * NWV;               // query rows per workgroup
     constexpr int D = DD;                      // compiled head_dim: 128 or 64
     static_assert(D == 128 || (D == 64 && !QK8), "head_dim 64 has no fp8 Q/K variant");
     constexpr int NG = D / 64;                 // groups of four head_dim tiles in the P V product
     constexpr int VG = 4;
-    constexpr int NWAVES = 8;
+    constexpr int NWAVES = NWV;
 #if defined(FA_DMA_SPREAD) && FA_DMA_SPREAD == 0
     constexpr bool SPREAD = false;
 #else
@@ -159,10 +165,10 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
     const int lg = lane >> 4;
 
     // waves w and w+4 share a SIMD: row blocks that sum to 7 balance the causal diagonal tile across SIMDs
-    const int rowblk_of_wave = CAUSAL ? (wave < 4 ? wave : 11 - wave) : wave;
-    const int q0w = qb * kBM + rowblk_of_wave * 32;
+    const int rowblk_of_wave = (CAUSAL && NWV == 8) ? (wave < 4 ? wave : 11 - wave) : wave;
+    const int q0w = qb * BM + rowblk_of_wave * 32;
 
-    const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * kBM + kBM + coff)) : Sk;   // (coff < 0: the first -coff queries see no key)
+    const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * BM + BM + coff)) : Sk;   // (coff < 0: the first -coff queries see no key)
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
     const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
 
     auto load_q = [&](int qblk, int lane_q) {     // (lane coordinates passed in: the call behind the main loop brings fresh ones)
         const int li = lane_q & 15, lg = lane_q >> 4;
-        const int row0 = qblk * kBM + rowblk_of_wave * 32;
+        const int row0 = qblk * BM + rowblk_of_wave * 32;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int qrow = row0 + 16 * qt + li;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             dma16(rv_w, __builtin_amdgcn_readfirstlane(piece_base + VBASE + stage_off + i * PIECE), (unsigned)j * v_tile_stride + g_voff[i]);
     };
 #if FA_HALF_PRIO
-    const int late_half = (wave >= 4) ? 1 : 0;
+    const int late_half = (NWV == 8 && wave >= 4) ? 1 : 0;      // (a lone wave per SIMD has no partner to yield to)
 #endif
     int stage_k = 0;                               // ring stage of tile j
     // piece I of the K(j + 3), V(j + 2) staging that follows barrier j (K pieces first); ring stage of tile j: ST if >= 0 (the
@@ -456,6 +462,9 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
         auto spread = [&] __device__ (auto r_c) {
             constexpr int R = decltype(r_c)::value;                  // region about to start
             if constexpr (DMA) {
+#if FA_DMA_SPREAD == 1 || FA_DMA_SPREAD == 2
+                static_assert(NWV == 8, "the experiment placements of the staging pieces exist for the 8-wave form only");
+#endif
 #if FA_DMA_SPREAD == 2          // two pieces in front of each S region
                 if constexpr (R == 1 || R == 3) {
                     dma_piece(IC<R - 1>{}, n >> 1, st_c);
@@ -463,10 +472,16 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
                 }
 #elif FA_DMA_SPREAD == 1        // one piece per region
                 dma_piece(r_c, n >> 1, st_c);
-#else                           // two pieces in front of each PV region (measured: the three placements are within noise)
+#else                           // half of the tile's pieces in front of each PV region (measured: the three placements are within noise)
                 if constexpr (R == 0 || R == 2) {
-                    dma_piece(IC<R>{}, n >> 1, st_c);
-                    dma_piece(IC<R + 1>{}, n >> 1, st_c);
+                    constexpr int HP = (CPTK + CPT + 1) / 2, I0 = (R / 2) * HP;      // (8-wave form: 2 + 2 pieces; 4-wave form: 4 + 4)
+                    dma_piece(IC<I0>{}, n >> 1, st_c);
+                    dma_piece(IC<I0 + 1>{}, n >> 1, st_c);
+                    if constexpr (HP > 2) {
+                        dma_piece(IC<I0 + 2>{}, n >> 1, st_c);
+                        dma_piece(IC<I0 + 3>{}, n >> 1, st_c);
+                    }
+                    static_assert(HP <= 4, "more pieces per tile than the spread schedule places");
                 }
 #endif
             }
@@ -842,8 +857,13 @@ __global__ __launch_bounds__(512, DD == 64 ? 4 : 2) void fa_fwd_kernel16(const F
             }
         });
         __syncthreads();
-        const u32x4 f0 = lds_read_b128(flags), f1 = lds_read_b128(flags + 16);
-        redo = __builtin_amdgcn_readfirstlane(f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0;
+        const u32x4 f0 = lds_read_b128(flags);
+        unsigned any_bad = f0[0] | f0[1] | f0[2] | f0[3];
+        if constexpr (NWV == 8) {
+            const u32x4 f1 = lds_read_b128(flags + 16);
+            any_bad |= f1[0] | f1[1] | f1[2] | f1[3];
+        }
+        redo = __builtin_amdgcn_readfirstlane(any_bad) != 0;
     }
     if (redo) {
         if (FA_CONT_EARLY_Q && cont) load_q(qb, lane_here());  // (the registers already hold the next block's fragments)

@@ -167,3 +167,27 @@ def test_strong_split_shards_are_the_unsharded_result():
         for r in range(world):
             lo, hi = shard_bounds(B * H, r, world)
             assert torch.equal(fa.flash_attn(qf[:, lo:hi], kf[:, lo:hi], vf[:, lo:hi], True), ref[:, lo:hi])
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_few_head_shards_run_on_128_row_workgroups_and_match_bitwise(causal, dt):
+    """The per-GPU shards of a strong split can be a few heads only (cfg4: 2 of 16 heads at W = 8): their 256-row grid would leave
+    most CUs without a workgroup, so the host launches the 128-row form of the head_dim-128 kernel (4 waves, one per SIMD:
+    fa_capi.hip rows_per_wg).  A wave does the same arithmetic in both forms: the shard must be BITWISE the slice of the full
+    launch (which runs the 256-row form), here for 1-, 2- and 3-head shards of a 32-head problem."""
+    import ctypes
+    B, H, S, D = 1, 32, 4096, 128
+    g = torch.Generator().manual_seed(41)
+    q, k, v = (torch.randn(B, H, S, D, generator=g).to(dt).cuda() for _ in range(3))
+    full, lse_full = fa.flash_attn(q, k, v, causal, return_lse=True)
+    lib = fa.load_library()
+    code = 0 if dt == torch.bfloat16 else 1
+    grid, block = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.fa_fwd_launch_info(B, H, S, D, code, int(causal), ctypes.byref(grid), ctypes.byref(block), None) == 0
+    assert block.value == 512                                        # the full launch: 8 waves
+    for h0, n in ((0, 1), (3, 2), (29, 3)):
+        assert lib.fa_fwd_launch_info(B, n, S, D, code, int(causal), ctypes.byref(grid), ctypes.byref(block), None) == 0
+        assert block.value == 256, (n, grid.value, block.value)      # the shard: 4 waves
+        o, lse = fa.flash_attn(q[:, h0:h0 + n], k[:, h0:h0 + n], v[:, h0:h0 + n], causal, return_lse=True)
+        assert torch.equal(o, full[:, h0:h0 + n]) and torch.equal(lse, lse_full[:, h0:h0 + n])
