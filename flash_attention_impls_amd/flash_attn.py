@@ -270,6 +270,7 @@ def _fwd_raw(lib, q, k, v, causal: bool, scale: float, descale, want_lse: bool):
 
 _ds_refused: dict = {}          # (device index, bytes) of hand-off workspaces that did not fit -> [calls left before the next look, current back-off]
 _plan_cache: dict = {}          # (shape, device, CU count, environment switches) -> (batches per launch, heads per launch, hand-off bytes or 0, recompute bytes)
+_ds_granted: set = set()       # (device index, bytes) of hand-off workspaces the allocator has provided before
 _ws_poison = False              # test hook (tests/test_bwd_ds_gpu.py): fill every backward workspace with 0xFF before it is used
 
 
@@ -343,15 +344,20 @@ def _bwd_plan(lib, dims, device):
         if state is not None and state[0] > 0:      # did not fit a moment ago: the recompute path for the next calls, then one more look
             state[0] -= 1
         else:
-            ok = _ds_fits(device, big)
+            # the allocator's figures are consulted on the FIRST call of a (device, size) and after a refusal only (they cost
+            # up to a millisecond: torch builds its whole statistics table); once a workspace of this size has been had, the
+            # caching allocator hands the same block back call after call and the hot path is one torch.empty
+            ok = (dev_idx, big) in _ds_granted or _ds_fits(device, big)
             if ok:
                 try:
                     ws = torch.empty(big, dtype=torch.uint8, device=device)
-                except torch.cuda.OutOfMemoryError:          # (fragmentation: the figures said yes, the allocator could not)
+                except torch.cuda.OutOfMemoryError:          # (memory got tight since, or fragmentation)
                     ok = False
             if ok:
+                _ds_granted.add((dev_idx, big))
                 _ds_refused.pop((dev_idx, big), None)
             else:
+                _ds_granted.discard((dev_idx, big))
                 back = min(1024, 2 * state[1]) if state is not None else 1
                 _ds_refused[(dev_idx, big)] = [back, back]
     if ws is None:
