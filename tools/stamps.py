@@ -17,6 +17,7 @@ ap.add_argument("--B", type=int, default=8)
 ap.add_argument("--H", type=int, default=32)
 ap.add_argument("--S", type=int, default=4096)
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"])
+ap.add_argument("--n-wg", type=int, default=0, help="workgroups of the launch if not B*H*blocks (experiment builds with a longer grid)")
 a = ap.parse_args()
 lib = fa.load_library()
 lib.fa_debug_read_stamps.restype = ctypes.c_int
@@ -39,7 +40,7 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 wall_us = e0.elapsed_time(e1) / 20 * 1e3
-n_wg = min(8192, a.B * a.H * ((a.S + 255) // 256) // (2 if a.causal else 1))
+n_wg = min(8192, a.n_wg or a.B * a.H * ((a.S + 255) // 256) // (2 if a.causal else 1))
 buf = np.zeros((n_wg, 8, 24), dtype=np.uint64)
 rc = lib.fa_debug_read_stamps(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
@@ -47,7 +48,11 @@ f = buf.astype(np.float64)
 tiles = f[:, :, 3]
 ok = tiles > 0
 n_seen = int(ok.any(axis=1).sum())
-if n_seen < n_wg:          # persistent launch: fewer workgroups than grid slots, each walks n_wg / n_seen items (sums below are per WORKGROUP)
+if a.n_wg:                 # experiment grid with workgroups that leave at once (no record): keep those that did work
+    keep = ok.any(axis=1)
+    buf, f, tiles, ok = buf[keep], f[keep], tiles[keep], ok[keep]
+    n_wg = n_seen
+elif n_seen < n_wg:        # persistent launch: fewer workgroups than grid slots, each walks n_wg / n_seen items (sums below are per WORKGROUP)
     print(f"persistent launch: {n_seen} workgroups for {n_wg} grid slots ({n_wg / max(1, n_seen):.1f} items per workgroup; the sums below are per workgroup, i.e. over its items)")
     buf, f, tiles, ok = buf[:n_seen], f[:n_seen], tiles[:n_seen], ok[:n_seen]
     n_wg = n_seen
@@ -124,6 +129,10 @@ if f[:, 0, 6].max() > 0:
     print(f"  first start of a CU after the launch's first: median {np.median(firsts):.2f} us, max {firsts.max():.2f} us")
     print(f"  gap between consecutive workgroups of a CU: median {np.median(gaps):.2f} us, mean {gaps.mean():.2f}, p90 {np.quantile(gaps, 0.9):.2f}, max {gaps.max():.2f}  (x {len(gaps) / len(per_cu):.1f} per CU = {gaps.sum() / len(per_cu):.1f} us per CU)")
     print(f"  last end of a CU before the launch's last end: median {np.median(span - lasts):.1f} us, mean {(span - lasts).mean():.1f}, max {(span - lasts).max():.1f}  (the tail)")
+    for x in np.unique(xcc):
+        m = xcc == x
+        print(f"    XCC {x}: {int(m.sum())} workgroups that did work, busy {((end - start)[m].sum() / 100.0 / 32):.1f} us per CU, last end {(end[m].max() - t0) / 100.0:.1f} us, "
+              f"workgroups started after 85 % of the launch: {int((start[m] - t0 > 0.85 * (end.max() - t0)).sum())}")
     life = (end - start) / 100.0
     print(f"  workgroup lifetime: mean {life.mean():.1f} us, p10 {np.quantile(life, 0.1):.1f}, p90 {np.quantile(life, 0.9):.1f}; by XCC: " +
           " ".join(f"{life[xcc == x].mean():.1f}" for x in np.unique(xcc)))
