@@ -26,7 +26,8 @@
     defined(FA8_GAP_FREE) || defined(FA_FP8_K32) || defined(FA_FP8_PV_BF16) || defined(FA_FP8_CONVERT_ALL) || defined(FA_BWD_ONLY) || \
     defined(FA_BWD_DKDV_SINGLE) || defined(FA_BWD_EXPERIMENTS) || defined(FA_BWD_DS_DISABLE) || defined(FA_BWD_DS_ALWAYS) || \
     defined(FA_BWD_DS_STORE_AUX) || defined(FA_BWD_DS_LOAD_NT) || defined(FA_BWD_DMA_ALL) || defined(FA_FWD_EXPERIMENTS) || \
-    defined(FA8_SAMPLED_CHECK) || defined(FA_ROWS128_MFMA32)
+    defined(FA8_SAMPLED_CHECK) || defined(FA_ROWS128_MFMA32) || defined(FA8_EARLY_EPILOGUE) || defined(FA8_CONT_RING) || \
+    defined(FA8_ODD_UNMASKED)
 #define FA_BUILD_NON_DEFAULT 1
 #else
 #define FA_BUILD_NON_DEFAULT 0

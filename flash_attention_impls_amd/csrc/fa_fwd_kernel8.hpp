@@ -47,6 +47,18 @@ constexpr float kGapFree8 = FA8_GAP_FREE;
 #ifndef FA8_HALF_PRIO
 #define FA8_HALF_PRIO 1
 #endif
+// FA8_EARLY_EPILOGUE / FA8_CONT_RING: the pass end of fa_fwd_kernel16.hpp (a wave stores its output as soon as it has finished its
+// blocks, ONE barrier with per-wave verdict flags instead of three; the staging slots of a causal pair's first pass that would fetch
+// tiles past its diagonal fetch the second pass's first tiles instead, so that it starts without a prologue and without a wait)
+#ifndef FA8_EARLY_EPILOGUE
+#define FA8_EARLY_EPILOGUE 1
+#endif
+#ifndef FA8_CONT_RING
+#define FA8_CONT_RING 1
+#endif
+#ifndef FA8_ODD_UNMASKED
+#define FA8_ODD_UNMASKED 1
+#endif
 constexpr float kPRefTop8 = 8.0f;
 constexpr float kGapFloor8 = 12.0f;            // a score further than this below mx counts as mx - 12 in the mean (one very low key must not move the window)
 constexpr float kSumFloor8 = 0.92f;            // WANT_LSE: rounded row sum below this share of the exact one -> exact fallback (underflowed weight)
@@ -102,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_char*)smem;   // K ring [kStages][TILE], then V ring
+    __shared__ __attribute__((aligned(16))) unsigned fa_flags8[2][8];          // per-wave fallback verdicts, by pass parity (outside the ring)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #if defined(FA_STAMP)
     // diagnostic build only (tools/stamps.py --dtype fp8): cycle sums per wave, as in fa_fwd_kernel16.hpp -- (a) a steady-state
@@ -141,6 +154,8 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
 
     i32x8 qf[2];               // Q fragments [query tile]: 32 bytes per lane (chunks g and g + 4 of the row)
+    bool staged = false;       // the previous pass left this pass's first tiles in the ring, landed and published (cont)
+    int stage0 = 0;            // ring stage of this pass's tile 0 (a staged pass continues where the ring stood)
 
   for (int pass = 0; pass < n_pass; ++pass) {
     const int qb = CAUSAL ? ((pass == 0) ? p.nqb - 1 - tq : tq) : tq;
@@ -154,6 +169,12 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     const int nt = (kv_end_wg + kBN8 - 1) / kBN8;                     // 128-key tiles the workgroup stages
     const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN8 - 1) / kBN8;                   // tiles this wave computes on
+    // Continuous ring (as fa_fwd_kernel16.hpp): the staging slots of the last three iterations fetch K(0..2), V(0..1) of the NEXT
+    // pass -- the same head -- instead of tiles past this pass's diagonal; the next pass's tile 0 then sits at ring stage
+    // (stage0 + nt) & 3 (128-key tiles: nt = 2 (qb + 1), so 0 or 2)
+    const bool cont = FA8_CONT_RING != 0 && FA8_EARLY_EPILOGUE != 0 && CAUSAL && (pass + 1 < n_pass) && nt >= kStages;
+    const int ntw = cont ? nt : 0x3fffffff;                           // tile index wrap of the staging DMAs
+    auto tk = [&](int t) { return t >= ntw ? t - ntw : t; };
 
     auto load_q = [&](int qblk, int lane_q) {
         const int li_ = lane_q & 15, lg_ = lane_q >> 4;
@@ -201,13 +222,13 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     // ---- LDS read addresses; they carry the ring stage of the tile being read (K: tile j, V: tile j - 1)
     unsigned ka[2];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) ka[hh] = lds_base + li * ROWB + (k8_swz(li, lg + 4 * hh) << 4);
+    for (int hh = 0; hh < 2; ++hh) ka[hh] = lds_base + stage0 * TILE + li * ROWB + (k8_swz(li, lg + 4 * hh) << 4);
     unsigned va[DT];
     {
         const int qq = li >> 1, pp = li & 1;
         const int key_in = 16 * (qq >> 2) + 4 * lg + (qq & 3);        // + 32 m: swizzle-neutral
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) va[dt] = lds_base + VBASE + key_in * ROWB + (v8_swz(key_in, dt) << 4) + 8 * pp;
+        for (int dt = 0; dt < DT; ++dt) va[dt] = lds_base + VBASE + stage0 * TILE + key_in * ROWB + (v8_swz(key_in, dt) << 4) + 8 * pp;
     }
     constexpr int NFB = 2;     // K and V^T fragment double buffers (by region parity): read two regions ahead of their MFMAs
     i32x8 kf[NFB], vf[NFB];
@@ -347,26 +368,30 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     FA8_PHASE(10);              // (diagnostic) offsets, addresses, accumulator init
     if (pass == 0) issue_prologue();
     FA8_PHASE(11);              // (diagnostic) prologue DMAs issued
-    dma_wait<3 * CPT>();        // this wave's pieces of K(0), V(0) have landed ...
-    __syncthreads();            // ... and every wave's are visible
+    if (!staged) {
+        // this wave's pieces of K(0) (and, older, its Q fragments) have landed; V(0) may still be in flight: its first reader is the
+        // fragment read in region 7 of block 0, behind that block's own wait and barrier, which cover it
+        dma_wait<4 * CPT>();
+        __syncthreads();        // ... and every wave's are visible
+    }
     FA8_PHASE(0);               // pass start -> first tiles visible
 
-    int stage_k = 0;                               // ring stage of tile j
+    int stage_k = stage0;                          // ring stage of tile j
     auto sync_and_stage = [&](int j) {
 #if !defined(FA8_ABL_NOBARRIER)                    // (timing-only ablation builds: wrong results)
         dma_wait<2 * CPT>();                       // everything but the previous iteration's DMA has landed ...
         __syncthreads();                           // ... and is published; the stages refilled below are no longer read
 #endif
 #if !defined(FA8_ABL_NODMA)
-        dma_k(j + 3, ((stage_k + 3) & (kStages - 1)) * TILE);
-        dma_v(j + 2, ((stage_k + 2) & (kStages - 1)) * TILE);
+        dma_k(tk(j + 3), ((stage_k + 3) & (kStages - 1)) * TILE);
+        dma_v(tk(j + 2), ((stage_k + 2) & (kStages - 1)) * TILE);
 #endif
     };
     auto advance_k = [&]() {                       // K(j) -> K(j+1)
         const int d = (stage_k == kStages - 1) ? -(kStages - 1) * TILE : TILE;
         ka[0] += d; ka[1] += d;
     };
-    int stage_v = 0;                               // ring stage the V^T read addresses point at (block 1 reads V(0))
+    int stage_v = stage0;                          // ring stage the V^T read addresses point at (block 1 reads V(0))
     auto advance_v = [&]() {                       // V(t) -> V(t+1): in region 7 of every block but the first
         const int d = (stage_v == kStages - 1) ? -(kStages - 1) * TILE : TILE;
         stage_v = (stage_v + 1) & (kStages - 1);
@@ -503,12 +528,21 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 #if defined(FA_STAMP)
         st_last = stamp_now();  // (the steady loop's cycles are kept in the segment sums)
 #endif
-        for (; j < NT; ++j) {                          // an odd block out, diagonal / ragged blocks: masked form + buffer swap
+        if (FA8_ODD_UNMASKED != 0 && j < ja) {         // an odd unmasked block out: single form + buffer swap
+            block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, N_{}, N_{}, Y{}, Y{}, true, j);
+            swap_pf();
+            stage_k = (stage_k + 1) & (kStages - 1);
+            ++j;
+        }
+        for (; j < NT; ++j) {                          // diagonal / ragged blocks: masked form + buffer swap
             block8(IC<0>{}, Y{}, Y{}, Y{}, Y{}, Y{}, N_{}, Y{}, Y{}, true, j);
             swap_pf();
             stage_k = (stage_k + 1) & (kStages - 1);
         }
         FA8_PHASE(3);           // an odd block out, masked (diagonal / ragged) blocks
+        // this wave's last score product is issued: the next query block's Q fragments take the registers now and travel under
+        // the drain, the staging-only tiles and the normalisation
+        if (cont) load_q(tq, lane_here());
         // drain, "block" NT: the last slice, P V of block NT - 1 (tiles 0..6) and of block NT - 2 (tile 7) ...
         const bool sync_d = j < nt;
         block8(IC<0>{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, N_{}, sync_d, j);
@@ -517,6 +551,8 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         // ... and tile 7 of block NT - 1 (its V^T fragment was read in region 7 above)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) o_acc[7][qt] = mfma8(vf[0], pf[1][qt], o_acc[7][qt]);
+    } else if (cont) {
+        load_q(tq, lane_here());
     }
     for (; j < nt; ++j) {                              // remaining tiles of the workgroup: staging duty only
         sync_and_stage(j);
@@ -531,7 +567,6 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 #endif
     FA8_PHASE(5);               // drain + staging-only tiles
     float l_part[2] = {l_a[0] + l_b[0], l_a[1] + l_b[1]};
-    dma_wait<0>();
     bool bad_row = !(l_acc[0][0] < kPLimit8 && l_acc[1][0] < kPLimit8);
     if constexpr (WANT_LSE) {
         // second trigger, where the exact sums exist anyway: the rounded P of a row add up to clearly less than the exact P,
@@ -554,7 +589,71 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             bad_row = bad_row || (l_acc[qt][0] < kSampleGain8 * u);
         }
     }
+    // ---- epilogue (as fa_fwd_kernel16.hpp): everything that needs no memory first, `mid()` (the caller's wait for its staging DMAs
+    // and the next Q fragments), then the stores, which stay in flight across the barrier that follows
+    auto epilogue = [&] __device__ (auto mid) {
+        const int lane_e = lane_here();
+        const int li = lane_e & 15, lg = lane_e >> 4;
+        u32x4 outv[2][DT / 2];
+        float lsev[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float l = l_part[qt];                                       // exact row sum (LSE)
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float lq = l_acc[qt][0];                              // sum of the rounded P of query li (normalisation)
+            const float inv = (lq > 0.f) ? p.out_scale / lq : 0.f;      // flash_attn_cutlass.cu:446-452 guard
+            lsev[qt] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt += 2) {
+                const f32x4 oa = o_acc[dt][qt], ob = o_acc[dt + 1][qt];
+                unsigned a0 = T::pack2(oa[0] * inv, oa[1] * inv), a1 = T::pack2(oa[2] * inv, oa[3] * inv);
+                unsigned b0 = T::pack2(ob[0] * inv, ob[1] * inv), b1 = T::pack2(ob[2] * inv, ob[3] * inv);
+                auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                outv[qt][dt / 2] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+        mid();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qrow = q0w + 16 * qt + li;
+            if (p.lse != nullptr && lg == 0 && qrow < S) p.lse[((long long)b * p.H + h) * S + qrow] = lsev[qt];
+            elem_t* orow = oh + (long long)qrow * p.o_ss;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt += 2) {
+                const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
+                if (qrow < S && col < p.dv) *reinterpret_cast<u32x4*>(orow + col) = outv[qt][dt / 2];
+            }
+        }
+    };
+    auto no_mid = [] __device__ () {};
+#if FA8_EARLY_EPILOGUE
+    // A wave that has finished its blocks stores its output at once -- the result is final unless some wave of the workgroup asks
+    // for the exact loop, which then recomputes and stores every row again.  Each wave posts its verdict in a flag word of its own
+    // before the ONE barrier that also retires the ring and, on a continuous ring, publishes the next query block's first tiles.
+    bool redo;
+    {
+        const unsigned flags = (unsigned)(uintptr_t)(lds_char*)&fa_flags8[pass & 1][0];
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(bad_row) != 0;
+        if (lane_here() == 0) lds_write_b32(flags + 4 * wave, wave_bad ? 1u : 0u);
+        epilogue([&] __device__ () {
+            dma_wait<0>();                         // no DMA may still be writing LDS past this point; the next Q fragments are in
+            if (cont) {                            // (consumed here, so that hipcc places its own wait for them here, not behind the stores)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) asm volatile("" :: "v"(qf[qt]));
+            }
+        });
+        __syncthreads();
+        const u32x4 f0 = lds_read_b128(flags), f1 = lds_read_b128(flags + 16);
+        redo = __builtin_amdgcn_readfirstlane(f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0;
+    }
+    if (redo) {
+        if (cont) load_q(qb, lane_here());         // (the registers already hold the next block's fragments)
+#else
+    dma_wait<0>();
     if (wg_any(bad_row, lds_base + VBASE + (kStages - 1) * TILE, wave, lane_here(), NWAVES)) {
+#endif
         constexpr int KO = 0, VO = VBASE;
         const int lane_f = lane_here();
         const int li = lane_f & 15, lg = lane_f >> 4;
@@ -653,41 +752,32 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         m_c[1] = (m_r[1] == -INFINITY) ? 0.f : m_r[1] - 7.0f;
         dma_wait<0>();
         __syncthreads();
+#if FA8_EARLY_EPILOGUE
+        epilogue(no_mid);
+#endif
     }
 
-    FA8_PHASE(6);               // fallback check (two barriers: waiting for the slowest wave)
+    FA8_PHASE(6);               // fallback check
+    // ---- the next query block of a causal pair
+    staged = false;
     if (pass + 1 < n_pass) {
-        issue_prologue();
-        load_q(tq, lane_here());
+#if FA8_EARLY_EPILOGUE
+        if (cont && !redo) {                       // its first tiles and Q fragments are in place (continuous ring)
+            staged = true;
+            stage0 = (stage0 + nt) & (kStages - 1);
+        } else
+#endif
+        {
+            stage0 = 0;
+            issue_prologue();
+            load_q(tq, lane_here());
+        }
     }
 
     FA8_PHASE(7);               // (the next pass's prologue issue)
-    // ---- epilogue (as fa_fwd_kernel16.hpp)
-    const int lane_e = lane_here();
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int li = lane_e & 15, lg = lane_e >> 4;
-        float l = l_part[qt];                                       // exact row sum (LSE)
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        const float lq = l_acc[qt][0];                              // sum of the rounded P of query li (normalisation)
-        const float inv = (lq > 0.f) ? p.out_scale / lq : 0.f;      // flash_attn_cutlass.cu:446-452 guard
-        const int qrow = q0w + 16 * qt + li;
-        if (p.lse != nullptr && lg == 0 && qrow < S)
-            p.lse[((long long)b * p.H + h) * S + qrow] = (l > 0.f) ? (m_c[qt] + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : -INFINITY;
-        elem_t* orow = oh + (long long)qrow * p.o_ss;
-#pragma unroll
-        for (int dt = 0; dt < DT; dt += 2) {
-            const f32x4 oa = o_acc[dt][qt], ob = o_acc[dt + 1][qt];
-            unsigned a0 = T::pack2(oa[0] * inv, oa[1] * inv), a1 = T::pack2(oa[2] * inv, oa[3] * inv);
-            unsigned b0 = T::pack2(ob[0] * inv, ob[1] * inv), b1 = T::pack2(ob[2] * inv, ob[3] * inv);
-            auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-            auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-            u32x4 outv = {s0[0], s1[0], s0[1], s1[1]};
-            const int col = (lg & 1) ? (16 * (dt + 1) + 4 * (lg - 1)) : (16 * dt + 4 * lg);
-            if (qrow < S && col < p.dv) *reinterpret_cast<u32x4*>(orow + col) = outv;
-        }
-    }
+#if !FA8_EARLY_EPILOGUE
+    epilogue(no_mid);           // (old order: output normalised and stored while the next block's first tiles travel)
+#endif
     FA8_PHASE(4);               // epilogue: normalise, store
   }  // pass
 #undef FA8_PHASE
