@@ -648,6 +648,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         const u32x4 f0 = lds_read_b128(flags), f1 = lds_read_b128(flags + 16);
         redo = __builtin_amdgcn_readfirstlane(f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0;
     }
+    FA8_PHASE(4);               // epilogue: normalise, store; the pass-end barrier
     if (redo) {
         if (cont) load_q(qb, lane_here());         // (the registers already hold the next block's fragments)
 #else
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
 #endif
     }
 
-    FA8_PHASE(6);               // fallback check
+    FA8_PHASE(6);               // the exact fallback, where taken (FA8_EARLY_EPILOGUE = 0: the check's two barriers)
     // ---- the next query block of a causal pair
     staged = false;
     if (pass + 1 < n_pass) {
@@ -777,8 +778,8 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     FA8_PHASE(7);               // (the next pass's prologue issue)
 #if !FA8_EARLY_EPILOGUE
     epilogue(no_mid);           // (old order: output normalised and stored while the next block's first tiles travel)
-#endif
     FA8_PHASE(4);               // epilogue: normalise, store
+#endif
   }  // pass
 #undef FA8_PHASE
 #if defined(FA_STAMP)

@@ -16,7 +16,8 @@ timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --rehearse-gather
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --force-dist --dist-backend nccl --steps 10 --warmup 3 --no-cpu-baseline --no-attainable > $O/bench_n1_nccl.json 2> $O/bench_n1_nccl.err &&
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 1 --force-dist --dist-backend nccl --scaling strong --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-attainable > $O/bench_n1_nccl_strong_cfg4.json 2> $O/bench_n1_nccl_strong_cfg4.err &&
 python bench.py --workload cfg5 --scaling strong --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_cfg5_strong_world1.json 2> $O/bench_cfg5_strong_world1.err &&
-timeout -k 10 400 python tools/shard_shapes.py > $O/shard_shapes.txt 2> $O/shard_shapes.err
+timeout -k 10 400 python tools/shard_shapes.py > $O/shard_shapes.txt 2> $O/shard_shapes.err &&
+timeout -k 10 400 python tools/compare_sdpa.py > $O/compare_torch_sdpa.txt 2> $O/compare_torch_sdpa.err
 echo rc=$?
 if [ -f build/libstamp.so ]; then
   FA_MI355_LIB=build/libstamp.so python tools/stamps.py --causal 0 > $O/stamps_cfg3.txt 2>&1

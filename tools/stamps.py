@@ -77,7 +77,7 @@ names = ["pass start -> first tiles visible", "fill iteration", "unrolled steady
          "  entry: parameters, decode, descriptors", "  Q loads issued", "  offsets, addresses, accumulator init", "  prologue DMAs issued"]
 if a.dtype == "fp8":
     names = ["pass start -> first tiles visible", "reference pre-pass (first block)", "fill block + steady pairs", "odd block out, masked blocks",
-             "epilogue: normalise, store", "drain + staging-only tiles", "fallback check (two barriers)", "next pass's prologue issue",
+             "epilogue: normalise, store, pass-end barrier", "drain + staging-only tiles (+ next Q loads)", "exact fallback (where taken)", "next pass's prologue issue (staged: none)",
              "  entry: parameters, decode, descriptors", "  Q loads issued", "  offsets, addresses, accumulator init", "  prologue DMAs issued"]
 print("(the first phase below is what remains after the four indented entry sub-phases: the wait for Q / K(0) and the barrier)")
 print("phases, cycles per workgroup (sum over its passes), mean over waves [older waves 0-3 | younger 4-7]:")
