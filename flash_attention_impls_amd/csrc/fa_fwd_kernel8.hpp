@@ -300,14 +300,26 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             pf[par][qt][kt] = pack_fp8(p2, p3, pack_fp8(p0, p1, pf[par][qt][kt], false), true);
         }
     };
-    // The row's FIRST 128-KEY BLOCK fixes its softmax reference and the place of its e4m3 window (kGapFree8 above), in a
-    // pre-pass of its own before the pipelined loop: the eight score tiles of the block are formed once more (16 MFMAs and
-    // ~100 VALU per wave and pass: < 1 % of a pass), only their row maximum, clamped sum and count are kept.  (Until round 3
-    // the first 16 keys alone decided: a row whose first 16 keys were ALL comparably dominant, with a broad tail 7 nats below
-    // them, got b = 0 and lost the tail -- a fifth of its weight at S = 4096 -- to e4m3's underflow, silently.  With 128 keys
-    // the tail is in the sample and opens the window downwards; what remains out of reach is a row whose first 128 keys are
-    // all dominant: the WANT_LSE variant then notices that the rounded and the exact row sums disagree and takes the exact
-    // loop, the variant without LSE has no exact sums to compare with -- stated in include/fa_mi355.h.)
+    // The row's FIRST 128-KEY BLOCK fixes its softmax reference and the place of its e4m3 window (kGapFree8 above): row maximum,
+    // clamped sum and count of its 128 scores.  (Until round 3 the first 16 keys alone decided: a row whose first 16 keys were ALL
+    // comparably dominant, with a broad tail 7 nats below them, got b = 0 and lost the tail -- a fifth of its weight at S = 4096 --
+    // to e4m3's underflow, silently.  With 128 keys the tail is in the sample and opens the window downwards; a row whose first 128
+    // keys are all dominant is caught at the pass end: the rounded against the exact row sums with an LSE, the sampled bound without.)
+    // Two forms.  The common one (`first_block_folded`, a block no row of the wave needs the mask in) forms the block's sixteen score
+    // tiles ONCE, into registers the O^T accumulators do not need yet, takes the statistics from them and then the eight softmax
+    // slices: it is block 0 of the pipeline as well.  The masked one (the first 128 rows of a causal head, a key length under 128)
+    // keeps the pre-pass of rounds 3 - 4: the tiles are formed for the statistics alone and once more by the pipeline's fill block.
+    auto place_window = [&] __device__ (const float (&mx)[2], const float (&sm)[2], const float (&sm2)[2], const float (&cn)[2]) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float m = mx[qt], u = sm[qt] + sm2[qt], n = cn[qt];
+            m = fmaxf(m, __shfl_xor(m, 16));   u += __shfl_xor(u, 16);   n += __shfl_xor(n, 16);
+            m = fmaxf(m, __shfl_xor(m, 32));   u += __shfl_xor(u, 32);   n += __shfl_xor(n, 32);
+            const float gap = (m - u * __builtin_amdgcn_rcpf(fmaxf(n, 1.f))) * c;               // 0 .. 12 binades
+            const float b = fminf(fmaxf(gap - kGapFree8, 0.f), kPRefTop8);                      // (a NaN gap gives 0)
+            m_c[qt] = (m == -INFINITY) ? 0.f : __builtin_fmaf(m, c, -b);
+        }
+    };
     auto set_reference_from_first_block = [&] __device__ (bool masked) {
         float mx[2] = {-INFINITY, -INFINITY}, sm[2] = {0.f, 0.f}, sm2[2] = {0.f, 0.f}, cn[2] = {0.f, 0.f};
         const float span = kGapFloor8 * __builtin_amdgcn_rcpf(c);
@@ -345,15 +357,7 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
             for (int kt = 0; kt < 8; ++kt) tile_stats(std::false_type{}, kt);
             cn[0] = cn[1] = 32.f;                                         // (8 tiles x 4 keys per lane)
         }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float m = mx[qt], u = sm[qt] + sm2[qt], n = cn[qt];
-            m = fmaxf(m, __shfl_xor(m, 16));   u += __shfl_xor(u, 16);   n += __shfl_xor(n, 16);
-            m = fmaxf(m, __shfl_xor(m, 32));   u += __shfl_xor(u, 32);   n += __shfl_xor(n, 32);
-            const float gap = (m - u * __builtin_amdgcn_rcpf(fmaxf(n, 1.f))) * c;               // 0 .. 12 binades
-            const float b = fminf(fmaxf(gap - kGapFree8, 0.f), kPRefTop8);                      // (a NaN gap gives 0)
-            m_c[qt] = (m == -INFINITY) ? 0.f : __builtin_fmaf(m, c, -b);
-        }
+        place_window(mx, sm, sm2, cn);
     };
 
     // ---- ring protocol (as fa_fwd_kernel.hpp, with 128-key tiles): iteration j reads K(j) (and K(j+1)'s first fragment in its
@@ -481,6 +485,46 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
         region(IC<0>{}); region(IC<1>{}); region(IC<2>{}); region(IC<3>{});
         region(IC<4>{}); region(IC<5>{}); region(IC<6>{}); region(IC<7>{});
     };
+    // Block 0 where no row of the wave needs the mask: what set_reference_from_first_block and the fill block do between them, with
+    // the sixteen score tiles formed once.  Leaves the pipeline exactly where the fill block leaves it: P of key tiles 0..6 in
+    // pf[0], the scores of key tile 7 in slot 1 (block 1's region 0 slices them), the first two K fragments of block 1 and the
+    // first V^T fragment of block 0 read, barrier(0) passed and K(3), V(2) requested.
+    auto first_block_folded = [&] __device__ () {
+        f32x4 s0[8][2];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            const u32x4 w0 = lds_read_b128(ka[0] + kt * 16 * ROWB), w1 = lds_read_b128(ka[1] + kt * 16 * ROWB);
+            const i32x8 kx = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) s0[kt][qt] = mfma8(kx, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        float mx[2] = {-INFINITY, -INFINITY}, sm[2] = {0.f, 0.f}, sm2[2] = {0.f, 0.f}, cn[2] = {32.f, 32.f};   // (8 tiles x 4 keys per lane)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {                              // (the unmasked statistics of set_reference_from_first_block, same order)
+                const f32x4 sx = s0[kt][qt];
+                mx[qt] = fmaxf(fmaxf(mx[qt], sx[0]), sx[1]);
+                mx[qt] = fmaxf(fmaxf(mx[qt], sx[2]), sx[3]);
+                sm[qt] += sx[0]; sm2[qt] += sx[1]; sm[qt] += sx[2]; sm2[qt] += sx[3];
+            }
+        place_window(mx, sm, sm2, cn);
+        sync_and_stage(0);
+        auto slice_of = [&] __device__ (auto kt_c) {
+            constexpr int kt = decltype(kt_c)::value;
+            s_acc[kt & 1][0] = s0[kt][0];
+            s_acc[kt & 1][1] = s0[kt][1];
+            sm_slice(std::false_type{}, IC<0>{}, kt_c, std::false_type{}, 0);      // (the first block is not sampled)
+        };
+        slice_of(IC<0>{}); slice_of(IC<1>{}); slice_of(IC<2>{}); slice_of(IC<3>{});
+        slice_of(IC<4>{}); slice_of(IC<5>{}); slice_of(IC<6>{});
+        s_acc[1][0] = s0[7][0];
+        s_acc[1][1] = s0[7][1];
+        advance_k();
+        read_k(IC<0>{}, IC<0>{});
+        read_k(IC<1>{}, IC<1>{});
+        read_v(IC<0>{}, IC<1>{});
+    };
     auto swap_pf = [&]() {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) { const i32x8 t = pf[0][qt]; pf[0][qt] = pf[1][qt]; pf[1][qt] = t; }
@@ -497,12 +541,17 @@ __global__ __launch_bounds__(512, 2) void fa_fwd_kernel8(const FwdParams p)
     const int mb = min(CAUSAL ? (max(0, q0w + coff) >> 7) : 0x7fffffff, Sk >> 7);
     int j = 0;
     if (NT > 0) {
-        set_reference_from_first_block(0 >= (min(CAUSAL ? (max(0, q0w + coff) >> 7) : 0x7fffffff, Sk >> 7)));   // (block 0 needs the mask)
-        FA8_PHASE(1);           // reference pre-pass over the first block
-        read_k(IC<0>{}, IC<0>{});
-        read_k(IC<1>{}, IC<1>{});
-        // block 0 (pipeline fill): scores and slices only (the reference is fixed: pre-pass above)
-        block8(IC<0>{}, Y{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, true, 0);
+        if (mb > 0) {           // block 0 needs no mask: scores once, then statistics and slices from them
+            first_block_folded();
+            FA8_PHASE(1);
+        } else {
+            set_reference_from_first_block(true);
+            FA8_PHASE(1);       // reference pre-pass over the first block
+            read_k(IC<0>{}, IC<0>{});
+            read_k(IC<1>{}, IC<1>{});
+            // block 0 (pipeline fill): scores and slices only (the reference is fixed: pre-pass above)
+            block8(IC<0>{}, Y{}, N_{}, Y{}, N_{}, Y{}, Y{}, N_{}, Y{}, true, 0);
+        }
         swap_pf();
         stage_k = (stage_k + 1) & (kStages - 1);
         j = 1;
