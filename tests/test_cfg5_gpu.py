@@ -337,3 +337,31 @@ def test_fp8_shapes_and_lse_variants(shape, causal):
     if fin.any():
         assert np.abs(got[fin] - lse_ref[fin]).max() <= 1e-3 * max(1.0, np.abs(lse_ref[fin]).max())
     assert (of[~fin] == 0).all()
+
+
+@pytest.mark.parametrize("Sn", [1024, 1280, 4096])
+@pytest.mark.parametrize("want_lse", [False, True])
+def test_fp8_causal_pairs_equal_single_block_launches_bitwise(Sn, want_lse):
+    """The causal fp8 launch of 256 heads runs query-block PAIRS (nqb-1-t, t) with the K / V ring streaming from the long pass into
+    the short one -- the short pass starts at ring stage 0 or 2, by the long pass's tile count: S = 1024 has both ((3,0): 8 tiles,
+    (2,1): 6), S = 1280 also a middle block that runs alone -- and forms block 0 once where no row needs the mask.  One query block
+    alone (its 256 rows against the keys up to its diagonal: S_q = 256, S_k = the block's end, bottom-right aligned mask) is a launch
+    without pairs and without a streamed ring.  Both must return the same bits: a wave's arithmetic does not depend on what its
+    workgroup did before."""
+    torch.manual_seed(Sn)
+    Bn, Hn = 8, 32
+    (q, sq), (k, sk), (v, sv) = [_quantise(torch.randn(Bn, Hn, Sn, D, device="cuda", dtype=torch.float32)) for _ in range(3)]
+    ds = (sq, sk, sv)
+    full = fa.flash_attn(q, k, v, True, descale=ds, return_lse=want_lse)
+    o_full, lse_full = full if want_lse else (full, None)
+    nqb = Sn // 256
+    for b, h in ((0, 0), (5, 17), (7, 31)):
+        for qb in sorted({0, 1, nqb // 2, nqb - 2, nqb - 1}):
+            r0, r1 = qb * 256, qb * 256 + 256
+            one = fa.flash_attn(q[b:b + 1, h:h + 1, r0:r1], k[b:b + 1, h:h + 1, :r1], v[b:b + 1, h:h + 1, :r1], True, descale=ds,
+                                return_lse=want_lse)
+            o_one, lse_one = one if want_lse else (one, None)
+            assert torch.equal(o_one.view(torch.int16), o_full[b:b + 1, h:h + 1, r0:r1].view(torch.int16)), (Sn, b, h, qb)
+            if want_lse:
+                assert torch.equal(lse_one, lse_full[b:b + 1, h:h + 1, r0:r1]), (Sn, b, h, qb)
+    assert torch.isfinite(o_full.float()).all()
