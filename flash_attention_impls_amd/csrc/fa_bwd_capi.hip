@@ -13,6 +13,7 @@
 #include "fa_bwd_kernel.hpp"
 #include "fa_bwd_dkdv_kernel.hpp"
 #include "fa_bwd_dq_gemm_kernel.hpp"
+#include "fa_bwd_wide_kernel.hpp"
 #include <cstdlib>
 
 namespace {
@@ -217,6 +218,22 @@ int bwd_grid(long long bh, long long blocks_per_head)
 {
     const long long g = fa_capi::grid_blocks(bh, blocks_per_head, fa_capi::head_split(bh, blocks_per_head));   // (virtual) heads padded to 8 XCD groups
     return g > 0x7FFFFFFFll ? -1 : (int)g;
+}
+
+// head_dim 144 .. 256: the P / dS producer of fa_bwd_wide_kernel.hpp
+template <class T, bool CAUSAL>
+int launch_wide_ds(const fa::BwdParams& p, int grid, hipStream_t stream)
+{
+    constexpr int lds = fa::kBwdWideLds;
+    auto* kernel = &fa::fa_bwd_wide_ds_kernel<T, CAUSAL>;
+    struct Tag {};
+    const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
+    if (attr_err != hipSuccess)
+        return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((fa::fa_bwd_wide_ds_kernel<T, CAUSAL>), dim3(grid), dim3(256), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
+    return FA_OK;
 }
 
 }  // namespace
@@ -428,6 +445,93 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
                                     : run_reduce<fa::TypeF16>(src, dst, B, H_kv, S_k, D, parts, so[0], so[1], so[2], s);
     }
     return rc;
+}
+
+size_t fa_bwd_wide_workspace_bytes(int B, int H, int S)
+{
+    if (B <= 0 || H <= 0 || S <= 0) return 0;
+    return stats_bytes(B, H, S);
+}
+
+int fa_bwd_wide_ds(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                   void* p_image, void* ds_image, long long ld,
+                   int B, int H, int H_kv, int S, int S_k, int D,
+                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                   const int64_t* o_strides, const int64_t* do_strides,
+                   int dtype, int causal, float softmax_scale,
+                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    g_err[0] = 0;
+    if (dtype != FA_DTYPE_BF16 && dtype != FA_DTYPE_FP16)
+        return fail(FA_ERR_BAD_DTYPE, "backward supports bf16 and fp16 (dtype code %d)", dtype);
+    if (D <= 128 || D > fa::kBwdWideD || D % 16 != 0)
+        return fail(FA_ERR_BAD_HEAD_DIM, "fa_bwd_wide_ds serves head_dim 144 .. %d (multiples of 16); got %d (fa_bwd_ex serves 16 .. 128)", fa::kBwdWideD, D);
+    if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape B=%d H=%d S=%d", B, H, S);
+    if (B == 0 || H == 0 || S == 0) return FA_OK;
+    if (H_kv <= 0 || H % H_kv != 0)
+        return fail(FA_ERR_BAD_SHAPE, "H=%d query heads are not a multiple of H_kv=%d key/value heads", H, H_kv);
+    if (S_k <= 0) return fail(FA_ERR_BAD_SHAPE, "S_k=%d: no keys", S_k);
+    if (ld < S_k || ld % 8 != 0) return fail(FA_ERR_BAD_STRIDE, "image row stride ld=%lld must be a multiple of 8 and >= S_k=%d", ld, S_k);
+    if (!q || !k || !v || !o || !d_o || !lse || !p_image || !ds_image || !workspace)
+        return fail(FA_ERR_NULL_PTR, "null tensor / image / workspace pointer");
+    if (workspace_bytes < fa_bwd_wide_workspace_bytes(B, H, S))
+        return fail(FA_ERR_BAD_SHAPE, "workspace too small: %zu < %zu bytes", workspace_bytes, fa_bwd_wide_workspace_bytes(B, H, S));
+
+    long long st[5][3];
+    const int64_t* given[5] = {q_strides, k_strides, v_strides, o_strides, do_strides};
+    const void* ptrs[7] = {q, k, v, o, d_o, p_image, ds_image};
+    long long max_ss = 0;
+    const int heads[5] = {H, H_kv, H_kv, H, H};
+    const int rows[5] = {S, S_k, S_k, S, S};
+    for (int i = 0; i < 5; ++i) {
+        if (!set_strides(given[i], heads[i], rows[i], D, st[i][0], st[i][1], st[i][2]))
+            return fail(FA_ERR_BAD_STRIDE, "strides must be non-negative with seq stride >= head_dim");
+        for (int c = 0; c < 3; ++c)
+            if ((st[i][c] * 2) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "stride %lld elements is not 16-byte aligned", st[i][c]);
+        max_ss = std::max(max_ss, st[i][2]);
+    }
+    for (int i = 0; i < 7; ++i)
+        if (reinterpret_cast<uintptr_t>(ptrs[i]) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "tensor / image base pointer not 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return fail(FA_ERR_BAD_STRIDE, "workspace not 16-byte aligned");
+    if (((long long)std::max(S, S_k) + 4 * fa::kBN) * max_ss * 2 >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "one (batch, head) slice spans >= 2 GiB (S=%d, seq stride=%lld)", std::max(S, S_k), max_ss);
+    const int Spad = (S + fa::kBN - 1) / fa::kBN * fa::kBN;
+    if ((long long)2 * B * H * Spad * 4 + 4 * fa::kBN * 4 >= (1ll << 31))
+        return fail(FA_ERR_TOO_LARGE, "row statistics exceed 2 GiB (B*H*S = %lld)", (long long)B * H * S);
+
+    const float scale = (softmax_scale > 0.f) ? softmax_scale : 1.0f / std::sqrt((float)D);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* stats = static_cast<float*>(workspace);
+    int rc = dtype == FA_DTYPE_BF16
+                 ? run_prep<fa::TypeBF16, fa::kBwdWideD>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s)
+                 : run_prep<fa::TypeF16, fa::kBwdWideD>(o, d_o, lse, stats, B, H, S, Spad, D, st[3][0], st[3][1], st[3][2], st[4][0], st[4][1], st[4][2], s);
+    if (rc != FA_OK) return rc;
+
+    fa::BwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.stats = stats;
+    p.B = B; p.H = H; p.S = S; p.dv = D; p.Spad = Spad; p.bh = B * H;
+    p.G = H / H_kv;
+    p.Sy = S_k;
+    p.coff = S_k - S;
+    p.scale = scale;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    p.x1 = q; p.x2 = d_o; p.y1 = k; p.y2 = v; p.out1 = p_image; p.out2 = ds_image;
+    p.x1_sb = st[0][0]; p.x1_sh = st[0][1]; p.x1_ss = st[0][2];
+    p.x2_sb = st[4][0]; p.x2_sh = st[4][1]; p.x2_ss = st[4][2];
+    p.y1_sb = st[1][0]; p.y1_sh = st[1][1]; p.y1_ss = st[1][2];
+    p.y2_sb = st[2][0]; p.y2_sh = st[2][1]; p.y2_ss = st[2][2];
+    p.o1_ss = p.o2_ss = ld;
+    p.o1_sh = p.o2_sh = (long long)S * ld;
+    p.o1_sb = p.o2_sb = (long long)H * S * ld;
+    p.nxb = (S + fa::kBwdWideRows - 1) / fa::kBwdWideRows;
+    p.unpaired = 1;
+    p.hsplit = fa_capi::head_split((long long)B * H, p.nxb);
+    const long long g = fa_capi::grid_blocks((long long)B * H, p.nxb, p.hsplit);
+    if (g > 0x7FFFFFFFll) return fail(FA_ERR_TOO_LARGE, "grid too large");
+    const bool c = causal != 0;
+    if (dtype == FA_DTYPE_BF16) return c ? launch_wide_ds<fa::TypeBF16, true>(p, (int)g, s) : launch_wide_ds<fa::TypeBF16, false>(p, (int)g, s);
+    return c ? launch_wide_ds<fa::TypeF16, true>(p, (int)g, s) : launch_wide_ds<fa::TypeF16, false>(p, (int)g, s);
 }
 
 }  // extern "C"

@@ -30,7 +30,7 @@ from . import _build
 FA_DTYPE_BF16 = 0
 FA_DTYPE_FP16 = 1
 FA_DTYPE_FP8_E4M3 = 2
-REFERENCE_MAX_HEAD_DIM = 128      # FA2-triton.py:178; the backward kernels stop here too
+REFERENCE_MAX_HEAD_DIM = 128      # FA2-triton.py:178; the fused backward kernels stop here too (144 .. 256: _bwd_wide)
 MAX_HEAD_DIM = 256                # forward, bf16 / fp16 (csrc/fa_fwd_kernel_wide.hpp)
 
 
@@ -118,6 +118,12 @@ def _declare(lib):
     lib.fa_fwd_launch_info.restype = c.c_int
     lib.fa_fwd_launch_info.argtypes = [c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int,
                                        c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    if hasattr(lib, "fa_bwd_wide_ds"):         # (FA_VERSION >= 136: backward for head_dim 144 .. 256)
+        lib.fa_bwd_wide_workspace_bytes.restype = c.c_size_t
+        lib.fa_bwd_wide_workspace_bytes.argtypes = [c.c_int] * 3
+        lib.fa_bwd_wide_ds.restype = c.c_int
+        lib.fa_bwd_wide_ds.argtypes = [c.c_void_p] * 6 + [c.c_void_p, c.c_void_p, c.c_longlong] + [c.c_int] * 6 + [c.c_void_p] * 5 + \
+            [c.c_int, c.c_int, c.c_float, c.c_void_p, c.c_size_t, c.c_void_p]
     if hasattr(lib, "fa_build_is_default"):    # (FA_VERSION >= 134)
         lib.fa_build_is_default.restype = c.c_int
         lib.fa_build_is_default.argtypes = []
@@ -385,6 +391,56 @@ def bwd_plan_info(q_shape, kv_shape, device=None) -> dict:
     return {"handoff": nbytes > small, "chunks": -(-B // bc) * -(-H // hc), "workspace_bytes": int(nbytes), "ds_bytes_full": int(full)}
 
 
+def _bwd_wide(lib, q, k, v, o, lse, do, causal: bool, scale: float):
+    """Backward for head_dim 144 .. 256 (include/fa_mi355.h, fa_bwd_wide_ds): the HIP kernel writes the P and the scaled dS image
+    of a chunk of heads, three library GEMMs (torch.bmm -> hipBLASLt) finish it -- dV = P^T dO, dK = dS^T Q, dQ = dS K, the
+    query heads of a key/value group stacked along the rows so that dK / dV come out summed over the group.  Chunks of whole
+    key/value groups keep the two images under FA_MI355_BWD_WIDE_MAX_GIB (default 4) of transient memory."""
+    if not hasattr(lib, "fa_bwd_wide_ds"):
+        raise RuntimeError("this build of the library has no backward for head_dim > 128 (fa_bwd_wide_ds, FA_VERSION >= 136)")
+    code = _dtype_code(q.dtype)
+    B, H, N, D = q.shape
+    Hkv, Nk = k.shape[1], k.shape[2]
+    G = H // Hkv
+    dq = torch.empty_like(o)
+    dk = torch.empty((B, Hkv, Nk, D), dtype=o.dtype, device=o.device)
+    dv = torch.empty_like(dk)
+    if B * H * N == 0:
+        return dq, dk.zero_(), dv.zero_()
+    do = _kernel_ready(do.to(q.dtype))
+    ld = -(-Nk // 8) * 8
+    cap = float(os.environ.get("FA_MI355_BWD_WIDE_MAX_GIB", "4")) * 2 ** 30
+    per_group = 2 * G * N * ld * 2                        # both images of one key/value group
+    gc = max(1, min(Hkv, int(cap // per_group)))           # key/value groups per chunk (one batch at a time)
+    with _on_device(q.device) as stream, _trace_range("FA2_BWD"):
+        images = torch.empty((2, gc * G, N, ld), dtype=q.dtype, device=q.device)
+        nbytes = lib.fa_bwd_wide_workspace_bytes(1, gc * G, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        for b in range(B):
+            for g0 in range(0, Hkv, gc):
+                g1 = min(Hkv, g0 + gc)
+                hq = slice(g0 * G, g1 * G)
+                qs, os_, dos, ls = q[b:b + 1, hq], o[b:b + 1, hq], do[b:b + 1, hq], lse[b:b + 1, hq]
+                ks, vs = k[b:b + 1, g0:g1], v[b:b + 1, g0:g1]
+                nh = (g1 - g0) * G
+                p_img, ds_img = images[0, :nh], images[1, :nh]
+                rc = lib.fa_bwd_wide_ds(qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), os_.data_ptr(), dos.data_ptr(),
+                                        ls.contiguous().data_ptr(), p_img.data_ptr(), ds_img.data_ptr(), ld,
+                                        1, nh, g1 - g0, N, Nk, D, _strides3(qs), _strides3(ks), _strides3(vs), _strides3(os_),
+                                        _strides3(dos), code, 1 if causal else 0, scale, ws.data_ptr(), nbytes, stream)
+                if rc != 0:
+                    raise RuntimeError(f"fa_bwd_wide_ds failed ({rc}): {lib.fa_last_error().decode()}")
+                # [group][G * N rows][keys]: the rows of a group's query heads stacked
+                p2 = p_img.view(g1 - g0, G * N, ld)[:, :, :Nk]
+                ds2 = ds_img.view(g1 - g0, G * N, ld)[:, :, :Nk]
+                q2 = qs[0].reshape(g1 - g0, G * N, D)
+                do2 = dos[0].reshape(g1 - g0, G * N, D)
+                dv[b, g0:g1] = torch.bmm(p2.transpose(1, 2), do2)
+                dk[b, g0:g1] = torch.bmm(ds2.transpose(1, 2), q2)
+                dq[b, hq] = torch.bmm(ds2, ks[0]).view(nh, N, D)
+    return dq, dk, dv
+
+
 def _bwd_raw(lib, q, k, v, o, lse, do, causal: bool, scale: float):
     """Launch the backward: pre-pass, then either dK/dV kernel (writing dS) + dQ GEMM, or dQ kernel + dK/dV kernel
     (recompute), by the workspace `_bwd_plan` could get.  Returns (dq, dk, dv), each written once."""
@@ -435,7 +491,8 @@ class FlashAttnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do, _dlse):
         q, k, v, o, lse = ctx.saved_tensors                   # :209
-        dq, dk, dv = _bwd_raw(load_library(), q, k, v, o, lse, do, ctx.causal, ctx.scale)
+        run = _bwd_wide if q.shape[3] > REFERENCE_MAX_HEAD_DIM else _bwd_raw
+        dq, dk, dv = run(load_library(), q, k, v, o, lse, do, ctx.causal, ctx.scale)
         return dq, dk, dv, None, None                         # :237
 
 
@@ -465,9 +522,6 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
     code = _dtype_code(q.dtype)
     if needs_grad and code == FA_DTYPE_FP8_E4M3:
         raise FlashAttnArgumentError("float8 inputs are forward-only (no backward kernel)")
-    if needs_grad and q.shape[3] > REFERENCE_MAX_HEAD_DIM:
-        raise FlashAttnArgumentError(f"head_dim {q.shape[3]} > {REFERENCE_MAX_HEAD_DIM} is forward-only (no backward kernel): "
-                                     "detach the inputs or run under torch.no_grad()")
     if descale is not None:
         # per-tensor dequantisation scales belong to float8 inputs; accepting them for 16-bit inputs on one path only
         # (the autograd Function takes none) would make the result depend on the grad mode
@@ -481,7 +535,7 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool =
         softmax_scale = 1.0 / math.sqrt(D_in)             # FA2-triton.py:183 (of the caller's head_dim)
     # Every head_dim the reference accepts (D % 16 == 0, D <= 128, :178) runs natively: the library picks the head_dim-64
     # or head_dim-128 kernel and the hardware's buffer bounds check supplies zeros for the columns past D (no padded
-    # copies on the host, nothing extra stored).  144 .. 256 run forward-only on the wide-head kernel.
+    # copies on the host, nothing extra stored).  144 .. 256 run on the wide-head kernels (backward: _bwd_wide).
     D = D_in
     if not lib.fa_supported(code, D):
         raise FlashAttnArgumentError(f"no gfx950 kernel for dtype={q.dtype}, head_dim={D}")

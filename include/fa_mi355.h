@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 135          /* 0.1.35: fp8 forward pass end of the 16-bit kernel (one barrier, continuous ring across a causal pair; results unchanged); 0.1.34: fp8 forward without LSE checks the whole row (sampled bound), fa_build_is_default; 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
+#define FA_VERSION 136          /* 0.1.36: backward for head_dim 144 .. 256 (fa_bwd_wide_ds + the caller's three GEMMs); 0.1.35: fp8 forward pass end of the 16-bit kernel (one barrier, continuous ring across a causal pair; results unchanged); 0.1.34: fp8 forward without LSE checks the whole row (sampled bound), fa_build_is_default; 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
@@ -233,6 +233,28 @@ int fa_bwd_ex(const void* q, const void* k, const void* v, const void* o, const 
               const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
               int dtype, int causal, float softmax_scale,
               void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Backward for wide heads, head_dim 144 .. 256 (this library's extension: the reference stops at 128, FA2-triton.py:178;
+ * SURVEY.md section 8(f) row N2 names 256).  At these head dims the fused backward kernels do not fit a register file, so the
+ * work is split where the head_dim stops mattering: fa_bwd_wide_ds runs the row-statistics pre-pass and ONE kernel
+ * (flash_attention_impls_amd/csrc/fa_bwd_wide_kernel.hpp) that forms S = Q K^T and dP = dO V^T on the matrix cores and writes
+ *   p_image [B,H,S_q,ld]  = P  = exp(scale * S [masked] - LSE)               (element type dtype, zeros where the mask hides a key)
+ *   ds_image[B,H,S_q,ld]  = scale * P o (dP - delta)
+ * contiguous, row stride ld (a multiple of 8, >= S_k; columns S_k .. ld-1 are written as zeros); every element is written.
+ * What remains are three plain GEMMs over the images, the caller's (any BLAS; this package's Python layer calls the vendor's batched GEMM):
+ *   dV = P^T dO,   dK = dS^T Q,   dQ = dS K        (per key/value head: summed over its group's query heads)
+ * A caller short of memory splits the call over batches or heads and reuses the images (2 * S_q * ld * 2 bytes per query head).
+ * workspace: fa_bwd_wide_workspace_bytes(B, H, S_q) bytes, 16-byte aligned.  Deterministic, no atomics.
+ */
+size_t fa_bwd_wide_workspace_bytes(int B, int H, int S_q);
+int fa_bwd_wide_ds(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                   void* p_image, void* ds_image, long long ld,
+                   int B, int H, int H_kv, int S_q, int S_k, int D,
+                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                   const int64_t* o_strides, const int64_t* do_strides,
+                   int dtype, int causal, float softmax_scale,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Launch geometry that fa_fwd would use (for benches / profilers): writes grid size,

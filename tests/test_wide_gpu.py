@@ -1,4 +1,5 @@
-"""GPU parity tests of the wide-head forward (head_dim 144 .. 256), csrc/fa_fwd_kernel_wide.hpp.
+"""GPU parity tests of the wide-head forward and backward (head_dim 144 .. 256), csrc/fa_fwd_kernel_wide.hpp
+and csrc/fa_bwd_wide_kernel.hpp.
 
 The reference rejects these shapes (assert D <= 128, FA2-triton.py:178), so no reference-generated fixture exists for them:
 parity is anchored on the float64 oracle, whose restatement of `sdpa_reference` has no head_dim-dependent branch and is
@@ -110,10 +111,91 @@ def test_wide_head_strided_inputs_fp32_round_trip_and_large_logits():
     check(q * 6, k * 6, v, True, "bf16", o, lse)
 
 
+BWD_CASES = [
+    # B, H, Hkv, Sq, Sk, D, dtype, causal
+    (1, 2, 2, 128, 128, 256, "bf16", False),
+    (1, 2, 2, 300, 300, 256, "bf16", True),       # ragged rows and keys, three query blocks
+    (2, 4, 2, 257, 700, 192, "bf16", True),       # grouped key/value heads (dK, dV summed over the group), offset 443
+    (1, 3, 3, 64, 64, 144, "fp16", False),        # the narrowest wide head
+    (1, 2, 1, 1, 300, 256, "bf16", True),         # one query
+    (1, 2, 2, 200, 77, 160, "fp16", False),       # fewer keys than queries, image rows padded 77 -> 80
+    (1, 2, 2, 300, 100, 256, "bf16", True),       # causal with fewer keys: the first 200 queries see no key (their dQ = 0)
+    (1, 6, 2, 513, 515, 240, "bf16", True),       # groups of three, offset 2
+    (2, 2, 2, 1024, 1024, 256, "bf16", True),     # eight query blocks per head, longest first
+]
+
+
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D,dt,causal", BWD_CASES)
+def test_wide_head_backward_vs_f64(B, H, Hkv, Sq, Sk, D, dt, causal):
+    """dQ, dK, dV of head_dim 144 .. 256 (csrc/fa_bwd_wide_kernel.hpp writes P and dS, three library GEMMs finish) against the
+    float64 oracle; parity unpinned by the reference, which stops at head_dim 128 -- anchored like the forward (module docstring)."""
+    from test_bwd_gpu import assert_grad_close
+    q, k, v = rand(B, H, Hkv, Sq, Sk, D, DT[dt], seed=Sq * 7 + Sk)
+    do = torch.randn(B, H, Sq, D, generator=torch.Generator().manual_seed(D)).to(DT[dt]).cuda()
+    leaves = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o = fa.flash_attn(*leaves, causal)
+    o.backward(do)
+    dq, dk, dv = [t.grad for t in leaves]
+    assert dk.shape == k.shape and dv.shape == v.shape and dq.shape == q.shape
+    G = H // Hkv
+    ke, ve = k.repeat_interleave(G, dim=1), v.repeat_interleave(G, dim=1)
+    qn, kn, vn, don = [t.float().cpu().numpy() for t in (q, ke, ve, do)]
+    dq_ref, dk_ref, dv_ref, _ = orc.naive_attention_bwd_f64(qn, kn, vn, don, causal=causal)
+    dk_ref = dk_ref.reshape(B, Hkv, G, Sk, D).sum(axis=2)
+    dv_ref = dv_ref.reshape(B, Hkv, G, Sk, D).sum(axis=2)
+    assert_grad_close(dq, dq_ref, dt, "dq")
+    assert_grad_close(dk, dk_ref, dt, "dk")
+    assert_grad_close(dv, dv_ref, dt, "dv")
+
+
+def test_wide_head_backward_properties():
+    """Zero-padded columns do not change the gradients of the columns that exist (head_dim 160 inside 256 against the same data as
+    head_dim 160), strided inputs, chunked images (a cap of a few MiB: one key/value group per launch) and determinism."""
+    import importlib
+    import os
+    fmod = importlib.import_module("flash_attention_impls_amd.flash_attn")
+    g = torch.Generator().manual_seed(11)
+    B, H, Hkv, S, D = 1, 4, 2, 384, 160
+    q, do = [torch.randn(B, H, S, D, generator=g).bfloat16().cuda() for _ in range(2)]
+    k, v = [torch.randn(B, Hkv, S, D, generator=g).bfloat16().cuda() for _ in range(2)]
+
+    def grads(qq, kk, vv, dd, causal=True):
+        leaves = [t.clone().requires_grad_(True) for t in (qq, kk, vv)]
+        fa.flash_attn(*leaves, causal, softmax_scale=D ** -0.5).backward(dd)
+        return [t.grad for t in leaves]
+
+    base = grads(q, k, v, do)
+    again = grads(q, k, v, do)
+    assert all(torch.equal(a, b_) for a, b_ in zip(base, again))
+    # the same problem embedded in head_dim 256 (zero columns): identical gradients on the first 160 columns, zeros beyond
+    pad = lambda t: torch.nn.functional.pad(t, (0, 256 - D))          # noqa: E731
+    wide = grads(pad(q), pad(k), pad(v), pad(do))
+    for a, b_, name in zip(base, wide, ("dq", "dk", "dv")):
+        assert torch.equal(a, b_[..., :D]), name
+        assert (b_[..., D:] == 0).all(), name
+    # strided views (a (B, S, H, D) buffer seen as (B, H, S, D))
+    qs = q.transpose(1, 2).contiguous().transpose(1, 2)
+    ks = k.transpose(1, 2).contiguous().transpose(1, 2)
+    strided = grads(qs, ks, v, do)
+    assert all(torch.equal(a, b_) for a, b_ in zip(base, strided))
+    # one key/value group per launch
+    prev = os.environ.get("FA_MI355_BWD_WIDE_MAX_GIB")
+    os.environ["FA_MI355_BWD_WIDE_MAX_GIB"] = "0.001"
+    try:
+        chunked = grads(q, k, v, do)
+    finally:
+        if prev is None:
+            os.environ.pop("FA_MI355_BWD_WIDE_MAX_GIB", None)
+        else:
+            os.environ["FA_MI355_BWD_WIDE_MAX_GIB"] = prev
+    assert all(torch.equal(a, b_) for a, b_ in zip(base, chunked))
+    assert fmod.MAX_HEAD_DIM == 256
+
+
 def test_wide_head_rules_backward_fp8_and_launch_info():
     q, k, v = rand(1, 2, 2, 64, 64, 256, torch.bfloat16, seed=1)
-    with pytest.raises(fa.FlashAttnArgumentError, match="forward-only"):
-        fa.flash_attn(q.requires_grad_(True), k, v, False)
+    o = fa.flash_attn(q.clone().requires_grad_(True), k, v, False)                                # differentiable since 0.1.36
+    assert o.requires_grad
     with pytest.raises(fa.FlashAttnArgumentError):
         fa.flash_attn(*rand(1, 1, 1, 32, 32, 272, torch.bfloat16, seed=1), False)              # > 256
     q8 = torch.zeros(1, 1, 32, 256, device="cuda").to(torch.float8_e4m3fn)

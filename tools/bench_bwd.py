@@ -25,6 +25,8 @@ CONFIGS = {
     "d64": (8, 32, 4096, 64, torch.bfloat16, True),
     "d64nc": (8, 32, 4096, 64, torch.bfloat16, False),
     "ref-main": (1, 16, 1024, 32, torch.float16, True),
+    "d256": (4, 16, 4096, 256, torch.bfloat16, True),          # wide heads: fa_bwd_wide_ds + three library GEMMs
+    "d256nc": (4, 16, 4096, 256, torch.bfloat16, False),
 }
 
 
@@ -44,7 +46,8 @@ def main():
         q, k, v, do = [torch.randn(B, H, S, D, device="cuda").to(dt) for _ in range(4)]
         scale = D ** -0.5
         o, lse = fmod._fwd_raw(lib, q, k, v, causal, scale, None, True)
-        mb = measure_latency(lambda: fmod._bwd_raw(lib, q, k, v, o, lse, do, causal, scale), warmup=3, iters=args.iters)
+        bwd = fmod._bwd_wide if D > 128 else fmod._bwd_raw
+        mb = measure_latency(lambda: bwd(lib, q, k, v, o, lse, do, causal, scale), warmup=3, iters=args.iters)
         mf = measure_latency(lambda: fmod._fwd_raw(lib, q, k, v, causal, scale, None, True), warmup=3, iters=args.iters)
         qg, kg, vg = [t.clone().requires_grad_(True) for t in (q, k, v)]
 

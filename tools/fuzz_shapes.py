@@ -18,7 +18,7 @@ for it in range(N):
     H = Hkv * G
     S = int(rng.choice([1, 17, 64, 100, 255, 256, 257, 500, 700, 1024, 1100, 1500])) if rng.random() < 0.7 else int(rng.integers(1, 1600))
     Sk = S if rng.random() < 0.5 else max(1, S + int(rng.integers(-300, 900)))
-    D = int(rng.choice([16, 32, 64, 96, 128])); dt = str(rng.choice(["bf16", "fp16"])); causal = bool(rng.random() < 0.6)
+    D = int(rng.choice([16, 32, 64, 96, 128, 128, 144, 176, 208, 256])); dt = str(rng.choice(["bf16", "fp16"])); causal = bool(rng.random() < 0.6)
     if B * H * S * Sk > 2e7:      # keep the float64 oracle quick
         continue
     g = torch.Generator().manual_seed(it)
