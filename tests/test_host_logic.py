@@ -284,6 +284,19 @@ def test_grouped_query_entry_points_validate_without_gpu():
     mqa = lib.fa_bwd_ex_workspace_bytes(8, 32, 1, 4096, 4096, 128)
     assert mqa == lib.fa_bwd_workspace_bytes(8, 32, 4096) + 2 * 8 * 1 * 8 * 4096 * 128 * 4                  # 8 parts, fp32 dK and dV
     assert lib.fa_bwd_ex_workspace_bytes(1, 6, 4, 8, 8, 128) == 0                                               # H % H_kv != 0
+    # the wide-head backward entry (head_dim 144 .. 256): its own head_dim range, image row stride, group rule -- before any launch
+    nw = lib.fa_bwd_wide_workspace_bytes(1, 6, 8)
+    assert nw == lib.fa_bwd_workspace_bytes(1, 6, 8) and lib.fa_bwd_wide_workspace_bytes(0, 6, 8) == 0
+    wide = lambda H, Hkv, Sk, D, ld, dtype=0: lib.fa_bwd_wide_ds(*([p] * 6), p, p, ld, 1, H, Hkv, 8, Sk, D, *([null] * 5), dtype, 0, 0.0, p, nw, null)  # noqa: E731
+    assert wide(6, 6, 8, 128, 8) == -2 and b"144" in lib.fa_last_error()             # fa_bwd_ex's range
+    assert wide(6, 6, 8, 272, 8) == -2
+    assert wide(6, 6, 8, 200, 8) == -2                                                # not a multiple of 16
+    assert wide(6, 4, 8, 256, 8) == -3 and b"H_kv" in lib.fa_last_error()
+    assert wide(6, 6, 0, 256, 8) == -3
+    assert wide(6, 6, 8, 256, 12) == -4 and b"ld" in lib.fa_last_error()             # not a multiple of 8
+    assert wide(6, 6, 9, 256, 8) == -4                                                # shorter than a row of keys
+    assert wide(6, 6, 8, 256, 8, dtype=2) == -1                                       # fp8: forward only
+    assert lib.fa_bwd_wide_ds(*([null] * 8), 8, 0, 6, 6, 8, 8, 256, *([null] * 5), 0, 0, 0.0, null, 0, null) == 0     # empty batch: nothing to do
     # host side: k, v may have a head count that divides q's; the "no CPU path" rule comes after the shape rules
     q, k = torch.zeros(1, 6, 8, 64), torch.zeros(1, 2, 8, 64)
     with pytest.raises(fa.FlashAttnArgumentError, match="no CPU path"):
