@@ -27,7 +27,7 @@
     defined(FA_BWD_DKDV_SINGLE) || defined(FA_BWD_EXPERIMENTS) || defined(FA_BWD_DS_DISABLE) || defined(FA_BWD_DS_ALWAYS) || \
     defined(FA_BWD_DS_STORE_AUX) || defined(FA_BWD_DS_LOAD_NT) || defined(FA_BWD_DMA_ALL) || defined(FA_FWD_EXPERIMENTS) || \
     defined(FA8_SAMPLED_CHECK) || defined(FA_ROWS128_MFMA32) || defined(FA8_EARLY_EPILOGUE) || defined(FA8_CONT_RING) || \
-    defined(FA8_ODD_UNMASKED)
+    defined(FA8_ODD_UNMASKED) || defined(FA_WIDE_QT) || defined(FA_BWD_WIDE_QT)
 #define FA_BUILD_NON_DEFAULT 1
 #else
 #define FA_BUILD_NON_DEFAULT 0

@@ -230,7 +230,7 @@ int launch_wide_ds(const fa::BwdParams& p, int grid, hipStream_t stream)
     const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((fa::fa_bwd_wide_ds_kernel<T, CAUSAL>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((fa::fa_bwd_wide_ds_kernel<T, CAUSAL>), dim3(grid), dim3(fa::kBwdWideThreads), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;

@@ -21,18 +21,27 @@
 
 namespace fa {
 
-constexpr int kBwdWideRows = 128;                          // query rows per workgroup (4 waves x 32, as fa_fwd_kernel_wide.hpp)
+constexpr int kBwdWideRows = 128;                          // query rows per workgroup (as fa_fwd_kernel_wide.hpp)
 constexpr int kBwdWideD = 256;                             // compiled head_dim
 constexpr int kBwdWideLds = 2 /*K, V*/ * 2 /*stages*/ * kBN * kBwdWideD * 2;
+#ifndef FA_BWD_WIDE_QT
+#define FA_BWD_WIDE_QT 2
+#endif
+constexpr int kBwdWideThreads = 512 / FA_BWD_WIDE_QT;
 
 // BwdParams as used here: x1 = Q, x2 = dO (stationary, H heads, S rows); y1 = K, y2 = V (streamed, H / G heads, Sy rows);
 // out1 = P image, out2 = dS image (o?_sb / o?_sh / o?_ss: element strides of [batch][head][query row], o?_ss = ld >= Sy rounded
 // up to 4); stats as everywhere ([2][B*H][Spad]: LSE log2(e), then -delta); nxb = 128-row query blocks per head.
-template <class T, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void fa_bwd_wide_ds_kernel(const BwdParams p)
+// QT = 16-row query tiles per wave, as in fa_fwd_kernel_wide.hpp: 2 = 4 waves x 32 rows, one wave per SIMD (the default here);
+// 1 = 8 waves x 16 rows, two waves per SIMD -- which the forward gains 17 - 28 % from and this kernel LOSES 5 - 20 % with
+// ((4,16,4096,256): 3.82 / 4.08 ms causal / non-causal against 4.01 / 4.94): it is bound by its stores (two images of 8-byte pieces
+// per lane), and halving the rows per wave doubles the fragment reads without adding anything the stores could hide behind.
+template <class T, bool CAUSAL, int QT = FA_BWD_WIDE_QT>
+__global__ __launch_bounds__(512 / QT, QT == 1 ? 2 : 1) void fa_bwd_wide_ds_kernel(const BwdParams p)
 {
+    static_assert(QT == 1 || QT == 2, "16 or 32 query rows per wave");
     constexpr int D = kBwdWideD;
-    constexpr int NWAVES = 4;
+    constexpr int NWAVES = 8 / QT;
     constexpr int KS = D / 32;
     constexpr int ROWB = D * 2;
     constexpr int TILE = kBN * ROWB;           // 32 KiB per K (or V) tile
@@ -74,18 +83,18 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_wide_ds_kernel(const BwdParams 
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
 
-    const int q0w = qb * kBwdWideRows + wave * 32;
+    const int q0w = qb * kBwdWideRows + wave * 16 * QT;
     const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * kBwdWideRows + kBwdWideRows + coff)) : Sk;
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
-    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
+    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 16 * QT + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
     const int ntk = (ld + kBN - 1) / kBN;                             // tiles of an image row
 
     // ---- Q and dO fragments (the forward's map): lane (li, lg) holds row q0w + 16 qt + li, columns 32 ks + 8 lg + 0..7
-    u32x4 qf[2][KS], gf[2][KS];
-    float lse2[2], ndelta[2];
+    u32x4 qf[QT][KS], gf[QT][KS];
+    float lse2[QT], ndelta[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int qrow = q0w + 16 * qt + li;
         const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.x1_ss * 2 + lg * 16) : 0x80000000u;
         const unsigned goff = (qrow < S) ? (unsigned)((long long)qrow * p.x2_ss * 2 + lg * 16) : 0x80000000u;
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_wide_ds_kernel(const BwdParams 
     };
     auto zero_tile = [&](int j) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) store_pair(qt, j * kBN + 16 * kt + 4 * lg, 0u, 0u, 0u, 0u);
     };
@@ -154,11 +163,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_wide_ds_kernel(const BwdParams 
         const unsigned st = (j & 1) * TILE;
         const int key0 = j * kBN;
 
-        f32x4 s_acc[4][2], d_acc[4][2];
+        f32x4 s_acc[4][QT], d_acc[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 s_acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 d_acc[kt][qt] = f32x4{ndelta[qt], ndelta[qt], ndelta[qt], ndelta[qt]};
             }
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_wide_ds_kernel(const BwdParams 
                 const u32x4 kf = lds_read_b128(ka[ks] + st + kt * 16 * ROWB);
                 const u32x4 vf = lds_read_b128(ka[ks] + VBASE + st + kt * 16 * ROWB);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < QT; ++qt) {
                     s_acc[kt][qt] = T::mfma16(kf, qf[qt][ks], s_acc[kt][qt]);
                     d_acc[kt][qt] = T::mfma16(vf, gf[qt][ks], d_acc[kt][qt]);
                 }
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_wide_ds_kernel(const BwdParams 
         }
         const bool need_mask = (key0 + kBN > Sk) || (CAUSAL && key0 + kBN - 1 > q0w + coff);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             const int qrow = q0w + 16 * qt + li;
             const int lim = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - key0 - 4 * lg;   // key 16 kt + e of this lane is kept iff 16 kt + e <= lim
 #pragma unroll

@@ -140,7 +140,7 @@ int launch_wide(const fa::FwdParams& p, int grid, hipStream_t stream)
     const hipError_t attr_err = fa_capi::ensure_dynamic_lds<Tag>(reinterpret_cast<const void*>(kernel), lds);
     if (attr_err != hipSuccess)
         return fail(FA_ERR_LAUNCH, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((fa::fa_fwd_kernel_wide<T, CAUSAL>), dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((fa::fa_fwd_kernel_wide<T, CAUSAL>), dim3(grid), dim3(fa::kWideThreads), lds, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "kernel launch failed: %s", hipGetErrorString(e));
     return FA_OK;
@@ -299,7 +299,7 @@ int fa_fwd_launch_info(int B, int H, int S, int D, int dtype, int causal, int* g
     if (B < 0 || H < 0 || S < 0) return fail(FA_ERR_BAD_SHAPE, "negative shape");
     if (D > 128) {
         if (grid) *grid = grid_wide(B, H, S, nullptr);
-        if (block) *block = 256;
+        if (block) *block = fa::kWideThreads;
         if (lds_bytes) *lds_bytes = fa::kWideLds;
         return FA_OK;
     }

@@ -5,8 +5,8 @@
 // algorithm (FA2-triton.py:60-85 -- running maximum, rescale, deferred 1/l) on the fragment maps of fa_fwd_kernel16.hpp,
 // without that kernel's software pipeline: at head_dim 256 the O^T accumulators alone are 128 registers per lane.
 //
-//   * workgroup = 4 waves x 32 query rows = 128 rows, one wave per SIMD (launch bound 1: the 512-register file, O^T and
-//     S^T accumulators in the accumulation half); Q fragments (8 k-steps x 2 query tiles) stay in registers;
+//   * workgroup = 128 query rows: 8 waves x 16 rows, two waves per SIMD within 256 registers (round 4; until then 4 waves x 32
+//     rows, one wave per SIMD -- QT below); Q fragments (8 k-steps per query tile) stay in registers;
 //   * 64-key tiles, K and V rows of 512 bytes staged by LDS-DMA into two stages each (2 x 2 x 32 KiB = 128 KiB), one
 //     barrier per tile: tile j + 1 travels while tile j is computed.  Rows are 0 mod 256 bytes like head_dim 128's, so the
 //     same 16-byte-chunk swizzles keep the row reads (K) and the transposed reads (V^T) conflict-free;
@@ -23,12 +23,21 @@ namespace fa {
 constexpr int kBMW = 128;                                  // query rows per workgroup
 constexpr int kWideD = 256;                                // compiled head_dim
 constexpr int kWideLds = 2 /*K, V*/ * 2 /*stages*/ * kBN * kWideD * 2;
+#ifndef FA_WIDE_QT
+#define FA_WIDE_QT 1
+#endif
+constexpr int kWideThreads = 512 / FA_WIDE_QT;            // 8 waves x 16 rows (default) or 4 waves x 32 rows
 
-template <class T, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void fa_fwd_kernel_wide(const FwdParams p)
+// QT = 16-row query tiles per wave: 2 (4 waves x 32 rows, one wave per SIMD, the whole register file) or 1 (8 waves x 16 rows,
+// two waves per SIMD within 256 registers: each K / V^T fragment then feeds one MFMA instead of two -- twice the LDS reads, 2048
+// cycles of the LDS array per tile against 3072 of the matrix pipe at head_dim 256 -- but a wave waiting for its fragments or at
+// the tile's barrier has a partner that computes; the plain loop below has no other latency hiding).  Same arithmetic per row.
+template <class T, bool CAUSAL, int QT = FA_WIDE_QT>
+__global__ __launch_bounds__(512 / QT, QT == 1 ? 2 : 1) void fa_fwd_kernel_wide(const FwdParams p)
 {
+    static_assert(QT == 1 || QT == 2, "16 or 32 query rows per wave");
     constexpr int D = kWideD;
-    constexpr int NWAVES = 4;
+    constexpr int NWAVES = 8 / QT;
     constexpr int KS = D / 32;                 // k-steps of the QK^T product (8)
     constexpr int DT = D / 16;                 // 16-wide head_dim tiles of O^T (16)
     constexpr int ROWB = D * 2;                // bytes per K / V row in LDS
@@ -66,17 +75,17 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_kernel_wide(const FwdParams p)
     const u32x4 rk_w = make_rsrc(kh, k_bytes);
     const u32x4 rv_w = make_rsrc(vh, v_bytes);
 
-    const int q0w = qb * kBMW + wave * 32;
+    const int q0w = qb * kBMW + wave * 16 * QT;
     const int kv_end_wg = CAUSAL ? max(0, min(Sk, qb * kBMW + kBMW + coff)) : Sk;
     const int nt = (kv_end_wg + kBN - 1) / kBN;                       // tiles the workgroup stages
-    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 32 + coff)) : Sk);
+    const int kv_end_w = (q0w >= S) ? 0 : (CAUSAL ? max(0, min(Sk, q0w + 16 * QT + coff)) : Sk);
     const int my_nt = (kv_end_w + kBN - 1) / kBN;                     // tiles this wave computes on
 
     // ---- Q fragments: lane (li, lg) holds Q[q0w + 16 qt + li][32 ks + 8 lg + 0..7]; rows past S and columns past the
     // runtime head_dim get an offset outside the descriptor and read as zeros
-    u32x4 qf[2][KS];
+    u32x4 qf[QT][KS];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int qrow = q0w + 16 * qt + li;
         const unsigned qoff = (qrow < S) ? (unsigned)((long long)qrow * p.q_ss * 2 + lg * 16) : 0x80000000u;
 #pragma unroll
@@ -122,13 +131,14 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_kernel_wide(const FwdParams p)
             va[dt] = lds_base + VBASE + row * ROWB + v_swz16(row, 2 * dt + (pp >> 1)) * 16 + 8 * (pp & 1);
     }
 
-    f32x4 o_acc[DT][2];
+    f32x4 o_acc[DT][QT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_r[2] = {-INFINITY, -INFINITY};     // running row maxima, times scale*log2(e)
-    float l_r[2] = {0.f, 0.f};                 // this lane's share of the row sums
+        for (int qt = 0; qt < QT; ++qt) o_acc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_r[QT], l_r[QT];                    // running row maxima, times scale*log2(e); this lane's share of the row sums
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_r[qt] = -INFINITY; l_r[qt] = 0.f; }
     const float c = p.scale_log2;
 
     if (nt > 0) stage_tile(0);
@@ -140,24 +150,24 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_kernel_wide(const FwdParams p)
         const unsigned st = (j & 1) * TILE;
         const int key0 = j * kBN;
 
-        f32x4 s_acc[4][2];
+        f32x4 s_acc[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) s_acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < QT; ++qt) s_acc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const u32x4 kf = lds_read_b128(ka[ks] + st + kt * 16 * ROWB);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) s_acc[kt][qt] = T::mfma16(kf, qf[qt][ks], s_acc[kt][qt]);
+                for (int qt = 0; qt < QT; ++qt) s_acc[kt][qt] = T::mfma16(kf, qf[qt][ks], s_acc[kt][qt]);
             }
         }
 
         const bool need_mask = (key0 + kBN > Sk) || (CAUSAL && key0 + kBN - 1 > q0w + coff);
-        u32x4 pf[2][2];                        // P^T fragments [query tile][32-key half]
-        float alpha[2];
+        u32x4 pf[QT][2];                       // P^T fragments [query tile][32-key half]
+        float alpha[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             const int qrow = q0w + 16 * qt + li;
             const int lim = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - key0 - 4 * lg;   // key 16 kt + e of this lane is kept iff 16 kt + e <= lim
             float mx = -INFINITY;
@@ -188,11 +198,11 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_kernel_wide(const FwdParams p)
             l_r[qt] = l_r[qt] * alpha[qt] + (la + lb);
             m_r[qt] = m_new;
         }
-        if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[1] != 1.f) != 0) {      // some row of the wave raised its maximum
+        if (__builtin_amdgcn_ballot_w64(alpha[0] != 1.f || alpha[QT - 1] != 1.f) != 0) {      // some row of the wave raised its maximum
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] *= alpha[qt];
+                for (int qt = 0; qt < QT; ++qt) o_acc[dt][qt] *= alpha[qt];
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -202,13 +212,13 @@ __global__ __launch_bounds__(256, 1) void fa_fwd_kernel_wide(const FwdParams p)
                 const u32x2 hi = lds_read_tr16_b64(va[dt] + st + (32 * kb + 16) * ROWB);
                 const u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = T::mfma16(vf, pf[qt][kb], o_acc[dt][qt]);
+                for (int qt = 0; qt < QT; ++qt) o_acc[dt][qt] = T::mfma16(vf, pf[qt][kb], o_acc[dt][qt]);
             }
     }
 
     // ---- epilogue (as fa_fwd_kernel16.hpp): combine the lane groups' row sums, normalise, store O and the LSE
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         float l = l_r[qt];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);

@@ -107,9 +107,9 @@ def test_launch_info_geometry():
     assert lib.fa_fwd_launch_info(8, 32, 4096, 64, 0, 0, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
     assert (g.value, b.value) == (8 * 32 * 16, 512)                      # a grid that fills the chip keeps 256 rows
     assert lib.fa_fwd_launch_info(1, 1, 8, 40, 0, 0, None, None, None) == -2
-    # wide heads: 128-row workgroups of 4 waves, two stages of 32 KiB K and V tiles, no causal pairing
+    # wide heads: 128-row workgroups of 8 waves x 16 rows, two stages of 32 KiB K and V tiles, no causal pairing
     assert lib.fa_fwd_launch_info(2, 8, 1000, 256, 1, 1, ctypes.byref(g), ctypes.byref(b), ctypes.byref(l)) == 0
-    assert (g.value, b.value, l.value) == (2 * 8 * 8, 256, 131072)
+    assert (g.value, b.value, l.value) == (2 * 8 * 8, 512, 131072)
     assert lib.fa_fwd_launch_info(1, 1, 8, 256, 2, 0, None, None, None) == -2          # fp8 stops at head_dim 128
 
 

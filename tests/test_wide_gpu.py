@@ -205,4 +205,4 @@ def test_wide_head_rules_backward_fp8_and_launch_info():
     assert lib.fa_supported(0, 256) == 1 and lib.fa_supported(1, 144) == 1 and lib.fa_supported(2, 144) == 0
     grid, block, lds = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.fa_fwd_launch_info(2, 8, 1000, 256, 0, 1, ctypes.byref(grid), ctypes.byref(block), ctypes.byref(lds)) == 0
-    assert (grid.value, block.value, lds.value) == (2 * 8 * 8, 256, 131072)
+    assert (grid.value, block.value, lds.value) == (2 * 8 * 8, 512, 131072)           # 128-row workgroups of 8 waves x 16 rows
