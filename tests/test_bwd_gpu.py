@@ -262,6 +262,7 @@ def test_try_max_batch_probe_bounded():
 def test_many_heads_backward():
     """B*H above the 65535 grid.y limit goes through the flattened pre-pass grid."""
     B, H, S, D = 70, 1000, 16, 64
+    torch.manual_seed(70)       # (the check below sums three bf16 gradients of values near 1: a seeded draw, not a new one per run)
     q = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     o = fa.flash_attn(q, q, q, True)
     o.backward(torch.ones_like(o))
@@ -269,7 +270,9 @@ def test_many_heads_backward():
     assert torch.isfinite(q.grad).all()
     ref = orc.naive_attention_bwd_f64(*[q.detach()[:1, :2].float().cpu().numpy()] * 3, np.ones((1, 2, S, D)), causal=True)
     got = q.grad[:1, :2].float().cpu().numpy()
-    assert np.abs(got - (ref[0] + ref[1] + ref[2])).max() < 3e-2
+    # q = k = v: autograd adds the three bf16 gradients in bf16 -- two roundings of up to 2^-8 at values in [1, 2) on top of the
+    # kernels' own TOL["bf16"] = 1.6e-2 (an unseeded draw once came to 3.14e-2 against the former 3e-2)
+    assert np.abs(got - (ref[0] + ref[1] + ref[2])).max() < 1.6e-2 + 3 * 2.0 ** -7
 
 
 def test_native_cli_runs_and_passes():
