@@ -137,21 +137,30 @@ __global__ __launch_bounds__(512 / QT, QT == 1 ? 2 : 1) void fa_bwd_wide_ds_kern
     for (int ks = 0; ks < KS; ++ks) ka[ks] = lds_base + li * ROWB + k_swz<128>(li, 4 * ks + lg) * 16;
 
     const float c = p.scale_log2;
-    // lane (li, lg) owns, of a 64-key tile, the keys 16 kt + 4 lg + 0..3 of query rows q0w + 16 qt + li: four 16-bit values = 8 bytes
-    // of an image row per (kt, qt)
-    auto store_pair = [&](int qt, int key, unsigned p_lo, unsigned p_hi, unsigned d_lo, unsigned d_hi) {
+    // lane (li, lg) owns, of a 64-key tile, the keys 16 kt + 4 lg + 0..3 of query rows q0w + 16 qt + li: two packed words per key
+    // tile.  Key tiles are stored in pairs (kt, kt + 1) with the forward epilogue's lane exchange (v_permlane16_swap: odd lane groups
+    // of the first tile's words <-> even groups of the second's), so that every lane stores 16 contiguous bytes -- even lg: keys
+    // 16 kt + 4 lg .. + 7, odd lg: keys 16 (kt + 1) + 4 (lg - 1) .. + 7 -- and one instruction covers 64 contiguous bytes of each row
+    // instead of 32 (with 8-byte stores the kernel spent most of its time on partial-line writes).
+    const int key_in_pair = (lg & 1) ? (16 + 4 * (lg - 1)) : 4 * lg;           // + 16 kt (kt even) + the tile's first key
+    auto store_pair = [&](elem_t* img, int qt, int key, unsigned a0, unsigned a1, unsigned b0, unsigned b1) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
         const int qrow = q0w + 16 * qt + li;
-        if (qrow < S && key < ld) {
-            const long long off = (long long)qrow * ld + key;
-            *reinterpret_cast<u32x2*>(ph + off) = u32x2{p_lo, p_hi};
-            *reinterpret_cast<u32x2*>(dh + off) = u32x2{d_lo, d_hi};
-        }
+        if (qrow < S && key < ld)                                              // (ld is a multiple of 8: a 16-byte piece is in or out whole)
+            *reinterpret_cast<u32x4*>(img + (long long)qrow * ld + key) = u32x4{s0[0], s1[0], s0[1], s1[1]};
     };
     auto zero_tile = [&](int j) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) store_pair(qt, j * kBN + 16 * kt + 4 * lg, 0u, 0u, 0u, 0u);
+            for (int kt = 0; kt < 4; kt += 2) {
+                const int qrow = q0w + 16 * qt + li, key = j * kBN + 16 * kt + key_in_pair;
+                if (qrow < S && key < ld) {
+                    *reinterpret_cast<u32x4*>(ph + (long long)qrow * ld + key) = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(dh + (long long)qrow * ld + key) = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
     };
 
     if (nt > 0) stage_tile(0);
@@ -188,17 +197,24 @@ __global__ __launch_bounds__(512 / QT, QT == 1 ? 2 : 1) void fa_bwd_wide_ds_kern
             const int qrow = q0w + 16 * qt + li;
             const int lim = (CAUSAL ? min(Sk - 1, qrow + coff) : Sk - 1) - key0 - 4 * lg;   // key 16 kt + e of this lane is kept iff 16 kt + e <= lim
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                float pv[4], dsv[4];
+            for (int kt = 0; kt < 4; kt += 2) {
+                unsigned pw[2][2], dw[2][2];                                   // [tile of the pair][word]
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kt][qt][e], c, -lse2[qt]));   // (a fully masked row has LSE = +inf here: 0)
-                    if (need_mask && 16 * kt + e > lim) x = 0.f;
-                    pv[e] = x;
-                    dsv[e] = x * d_acc[kt][qt][e] * p.scale;
+                for (int t = 0; t < 2; ++t) {
+                    float pv[4], dsv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kt + t][qt][e], c, -lse2[qt]));   // (a fully masked row has LSE = +inf here: 0)
+                        if (need_mask && 16 * (kt + t) + e > lim) x = 0.f;
+                        pv[e] = x;
+                        dsv[e] = x * d_acc[kt + t][qt][e] * p.scale;
+                    }
+                    pw[t][0] = T::pack2(pv[0], pv[1]);   pw[t][1] = T::pack2(pv[2], pv[3]);
+                    dw[t][0] = T::pack2(dsv[0], dsv[1]); dw[t][1] = T::pack2(dsv[2], dsv[3]);
                 }
-                store_pair(qt, key0 + 16 * kt + 4 * lg, T::pack2(pv[0], pv[1]), T::pack2(pv[2], pv[3]),
-                           T::pack2(dsv[0], dsv[1]), T::pack2(dsv[2], dsv[3]));
+                const int key = key0 + 16 * kt + key_in_pair;
+                store_pair(ph, qt, key, pw[0][0], pw[0][1], pw[1][0], pw[1][1]);
+                store_pair(dh, qt, key, dw[0][0], dw[0][1], dw[1][0], dw[1][1]);
             }
         }
     }
