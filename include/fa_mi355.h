@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define FA_VERSION 137          /* 0.1.37: wide-head forward on 8 waves x 16 rows (results unchanged, +17 .. 28 %); 0.1.36: backward for head_dim 144 .. 256 (fa_bwd_wide_ds + the caller's three GEMMs); 0.1.35: fp8 forward pass end of the 16-bit kernel (one barrier, continuous ring across a causal pair; results unchanged); 0.1.34: fp8 forward without LSE checks the whole row (sampled bound), fa_build_is_default; 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
+#define FA_VERSION 138          /* 0.1.38: wide-head backward images stored in 16-byte pieces (results unchanged); 0.1.37: wide-head forward on 8 waves x 16 rows (results unchanged, +17 .. 28 %); 0.1.36: backward for head_dim 144 .. 256 (fa_bwd_wide_ds + the caller's three GEMMs); 0.1.35: fp8 forward pass end of the 16-bit kernel (one barrier, continuous ring across a causal pair; results unchanged); 0.1.34: fp8 forward without LSE checks the whole row (sampled bound), fa_build_is_default; 0.1.33: dS hand-off backward (fa_bwd_ds_workspace_bytes); 0.1.32: fa_diag_mfma_loop, fa_device_cus; 0.1.31: head_dim 144 .. 256 forward (16-bit types); 0.1.3: fp8 P V on fp8 MFMAs, fa_fp8_pv_native (0.1.2: + extended entry points (H_kv, S_k); 0.1.1: + backward) */
 
 /* element types of Q/K/V (and of O unless stated otherwise) */
 #define FA_DTYPE_BF16     0
