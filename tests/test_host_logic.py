@@ -442,3 +442,31 @@ def test_default_build_sets_no_experiment_switch():
                     "FA_PERSIST_ON", "FA8_SAMPLED_CHECK_ON", "FA_SYNC_STAGE", "FA_SYNC_STAGE_C", "FA_ODD_BLOCK", "FA_PHASE", "FA8_PHASE"}
     missing = sorted(m for m in used - not_switches if m not in guard)
     assert not missing, f"switches tested by the sources but unknown to fa_build_guard.hpp: {missing}"
+
+
+def test_gpu_tests_draw_seeded_inputs():
+    """A GPU parity test must not depend on the draw: every `torch.randn(` / `torch.rand(` in tests/*_gpu.py either takes a
+    generator or sits behind a `manual_seed(` of its own function (or module fixture).  (Round 4 met one unseeded draw that failed a
+    3e-2 bound by 1.4e-3 on its 40th run.)  Uses whose VALUES are never compared are listed here."""
+    import ast
+    value_free = {("test_bwd_gpu.py", "test_bwd_fp8_is_forward_only"), ("test_bwd_gpu.py", "test_try_max_batch_probe_bounded")}
+    bad = []
+    tdir = os.path.join(ROOT, "tests")
+    for fn in sorted(os.listdir(tdir)):
+        if not fn.endswith("_gpu.py"):
+            continue
+        src = open(os.path.join(tdir, fn)).read()
+        tree = ast.parse(src)
+        for node in ast.walk(tree):
+            if not isinstance(node, (ast.FunctionDef,)):
+                continue
+            seg = ast.get_source_segment(src, node) or ""
+            calls = [m.start() for m in re.finditer(r"torch\.randn?\(", seg)]
+            for pos in calls:
+                call = seg[pos:seg.index("\n", pos) if "\n" in seg[pos:] else len(seg)]
+                if "generator=" in call:
+                    continue
+                if "manual_seed(" in seg[:pos] or (fn, node.name) in value_free:
+                    continue
+                bad.append((fn, node.name, call.strip()[:60]))
+    assert not bad, bad
